@@ -1,0 +1,701 @@
+// C ABI of libacg_ldpc_hip.so (include/acg_ldpc.h): handles, uploads, launches.
+// There is deliberately NO CPU decode path in this library: without a HIP device every decoder
+// entry point fails with an error code and message.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/acg_ldpc.h"
+#include "kernels.hpp"
+#include "ldpc_internal.hpp"
+
+namespace acg {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+hipError_t bp_launch(int algo, int f64, int maxd, int L, const BpTables &t, const DecodeArgs &a, int grid, int block,
+                     size_t lds, hipStream_t s);
+const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc);
+hipError_t phi_debug_launch(const void *x, void *out, int n, int f64, hipStream_t s);
+hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t first_frame, uint64_t seed,
+                       const uint32_t *cw_packed, int64_t n_cw, float sigma, hipStream_t s);
+
+struct AdmmDevice;  // admm_kernels.hip
+AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_count, std::string &err);
+void admm_device_destroy(AdmmDevice *d);
+hipError_t admm_launch(AdmmDevice *d, const DecodeArgs &a, hipStream_t s, std::string &err);
+void admm_device_layout(const AdmmDevice *d, int *lds_per_frame, int *lanes, int *frames_per_block, int *grid);
+
+#define HIP_OK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+            return 10;                                                                          \
+        }                                                                                       \
+    } while (0)
+
+template <typename T>
+static int upload(const std::vector<T> &h, T **d, size_t min_elems = 1) {
+    size_t n = std::max(h.size(), min_elems);
+    HIP_OK(hipMalloc((void **) d, n * sizeof(T)));
+    if (!h.empty()) HIP_OK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace acg
+
+using namespace acg;
+
+struct acg_ldpc_code {
+    Code c;
+};
+
+struct acg_ldpc_decoder {
+    Code c;  // private copy: the handle outlives the code object safely
+    acg_ldpc_params p;
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    std::mutex mu;
+    std::string name;
+    // BP
+    BpLayout lay;
+    BpTables tab{};
+    std::vector<void *> dev_allocs;
+    int maxd = 0, f64 = 0, L = 64;
+    int block = 256, grid_cap = 0, frames_per_block = 0;
+    size_t lds_block = 0;
+    // ADMM
+    AdmmDevice *admm = nullptr;
+    // staging for the host API
+    void *st_y = nullptr;
+    uint32_t *st_bits = nullptr;
+    uint8_t *st_ok = nullptr;
+    int32_t *st_iters = nullptr;
+    int64_t st_frames = 0;
+    // MC
+    uint32_t *cw_dev = nullptr;
+    int64_t cw_count = 0;
+    const uint8_t *cw_host_key = nullptr;
+    unsigned long long *counters = nullptr;
+};
+
+extern "C" {
+
+void acg_ldpc_params_default(acg_ldpc_params *p) {
+    std::memset(p, 0, sizeof(*p));
+    p->algo = ACG_LDPC_BP_SUMPRODUCT;
+    p->max_iter = 50;
+    p->alpha = 1.95;   // main.cpp:33
+    p->mu = 0.5;
+    p->eps_stop = 1e-5;  // qp_admm.h:182
+    p->ms_scale = 1.0;
+    p->early_exit = 1;
+    p->precision = ACG_LDPC_PREC_DEFAULT;
+    p->device = -1;
+    p->lanes_per_frame = 0;
+}
+
+const char *acg_ldpc_last_error(void) { return g_err.c_str(); }
+
+int acg_ldpc_device_available(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n > 0 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- code
+int acg_ldpc_code_from_dense(const uint8_t *H, int32_t m, int32_t n, acg_ldpc_code **out) {
+    if (!H || !out) {
+        set_error("null argument");
+        return 1;
+    }
+    auto *c = new acg_ldpc_code();
+    if (!code_build(c->c, H, m, n)) {
+        delete c;
+        return 2;
+    }
+    *out = c;
+    return 0;
+}
+
+int acg_ldpc_code_load_txt(const char *path, acg_ldpc_code **out) {
+    if (!path || !out) {
+        set_error("null argument");
+        return 1;
+    }
+    std::vector<uint8_t> H;
+    int m = 0, n = 0;
+    if (!code_read_txt(path, H, m, n)) return 2;
+    return acg_ldpc_code_from_dense(H.data(), m, n, out);
+}
+
+int acg_ldpc_code_save_txt(const acg_ldpc_code *code, const char *path) {
+    if (!code || !path) {
+        set_error("null argument");
+        return 1;
+    }
+    return code_write_txt(code->c, path) ? 0 : 2;
+}
+
+void acg_ldpc_code_destroy(acg_ldpc_code *code) { delete code; }
+
+void acg_ldpc_code_dims(const acg_ldpc_code *code, int32_t *m, int32_t *n, int32_t *E) {
+    if (m) *m = code->c.m;
+    if (n) *n = code->c.n;
+    if (E) *E = code->c.E;
+}
+
+void acg_ldpc_code_dense(const acg_ldpc_code *code, uint8_t *H) {
+    std::memcpy(H, code->c.H.data(), code->c.H.size());
+}
+
+void acg_ldpc_code_admm_shape(const acg_ldpc_code *code, int32_t *n_var, int32_t *n_con, int32_t *nnz, double *e_min,
+                              double *e_max) {
+    const AdmmLayout &a = code->c.admm;
+    if (n_var) *n_var = a.n_var;
+    if (n_con) *n_con = a.n_con;
+    if (nnz) *nnz = a.nnz;
+    if (e_min) *e_min = a.e_min;
+    if (e_max) *e_max = a.e_max;
+}
+
+int acg_ldpc_code_generator(const acg_ldpc_code *code, uint8_t *G) {
+    if (!code || !G) {
+        set_error("null argument");
+        return 2;
+    }
+    if (code->c.n <= code->c.m) {
+        set_error("generator needs n > m");
+        return 2;
+    }
+    return code_generator(code->c, G) ? 0 : 1;
+}
+
+int acg_ldpc_code_is_codeword(const acg_ldpc_code *code, const uint8_t *bits) {
+    return code_is_codeword(code->c, bits) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- decoder
+static int decoder_setup_bp(acg_ldpc_decoder *d) {
+    const Code &c = d->c;
+    d->maxd = std::max(c.max_cdeg, c.max_vdeg);
+    if (d->maxd > 32) {
+        set_error("node degree above 32 is not supported by the fused BP kernels");
+        return 3;
+    }
+    d->f64 = (d->p.precision == ACG_LDPC_PREC_F64) ? 1 : 0;
+    int L = d->p.lanes_per_frame;
+    if (L == 0) L = 64;
+    if (L != 16 && L != 32 && L != 64) {
+        set_error("lanes_per_frame must be 0, 16, 32 or 64");
+        return 3;
+    }
+    d->L = L;
+    if (!bp_layout_build(c, L, d->lay)) return 3;
+    BpLayout &lay = d->lay;
+    const int nwords = (c.n + 31) / 32;
+    // the MC path stages n symbols in the message array before clearing it
+    if (lay.a_words < ((c.n + 3) & ~3)) lay.a_words = (c.n + 3) & ~3;
+    const size_t ts = d->f64 ? 8 : 4;
+    const int llr_words = lay.n_vpass * L;
+    size_t per_frame = (size_t) (lay.a_words + llr_words) * ts + (size_t) nwords * 4;
+    per_frame = (per_frame + 15) & ~(size_t) 15;
+
+    BpTables &t = d->tab;
+    int32_t *p32 = nullptr;
+    uint16_t *p16 = nullptr;
+#define UP32(vec, field)                                       \
+    if (upload<int32_t>(vec, &p32)) return 10;                 \
+    d->dev_allocs.push_back(p32);                              \
+    t.field = p32;
+    UP32(lay.c_maxdeg, c_maxdeg)
+    UP32(lay.c_off, c_off)
+    UP32(lay.c_cnt_ge, c_cnt_ge)
+    UP32(lay.v_maxdeg, v_maxdeg)
+    UP32(lay.v_idx_off, v_idx_off)
+    UP32(lay.v_cnt_ge, v_cnt_ge)
+    UP32(lay.v_var, v_var)
+#undef UP32
+    if (upload<uint16_t>(lay.v_apos, &p16)) return 10;
+    d->dev_allocs.push_back(p16);
+    t.v_apos = p16;
+    t.n_cpass = lay.n_cpass;
+    t.n_vpass = lay.n_vpass;
+    t.a_words = lay.a_words;
+    t.zero_pos = lay.zero_pos;
+    t.m = c.m;
+    t.n = c.n;
+    t.nwords = nwords;
+    t.llr_words = llr_words;
+    t.lds_bytes_per_frame = (int) per_frame;
+
+    const int fpw = 64 / L;
+    // waves per block: as many as fit in 64 KiB of LDS (so several blocks share a CU), at most 4
+    int waves = 4;
+    while (waves > 1 && per_frame * fpw * waves > 160 * 1024 / 2) waves >>= 1;
+    if (per_frame * fpw * waves > 160 * 1024) {
+        set_error("frame state does not fit in LDS (160 KiB per CU)");
+        return 3;
+    }
+    d->block = waves * 64;
+    d->frames_per_block = waves * fpw;
+    d->lds_block = per_frame * fpw * waves;
+    const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
+    int per_cu = 0;
+    for (int mc = 0; mc < 2; mc++) {
+        const void *kp = bp_kernel_ptr(algo, d->f64, d->maxd, L, mc != 0);
+        if (!kp) {
+            set_error("no kernel instance for this configuration");
+            return 3;
+        }
+        if (d->lds_block > 64 * 1024)
+            HIP_OK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block));
+        int occ = 0;
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, d->block, d->lds_block));
+        if (occ < 1) occ = 1;
+        per_cu = (mc == 0) ? occ : std::min(per_cu, occ);
+    }
+    d->grid_cap = per_cu * d->cu_count;
+    return 0;
+}
+
+int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *params, acg_ldpc_decoder **out) {
+    if (!code || !params || !out) {
+        set_error("null argument");
+        return 1;
+    }
+    if (params->max_iter < 0) {
+        set_error("max_iter must be >= 0");
+        return 1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: libacg_ldpc_hip has no CPU fallback");
+        return 20;
+    }
+    auto *d = new acg_ldpc_decoder();
+    d->c = code->c;
+    d->p = *params;
+    int dev = params->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) {
+        set_error("device ordinal out of range");
+        delete d;
+        return 1;
+    }
+    d->device = dev;
+    int rc = 0;
+    do {
+        if (hipSetDevice(dev) != hipSuccess) { set_error("hipSetDevice failed"); rc = 10; break; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("hipGetDeviceProperties failed"); rc = 10; break; }
+        d->cu_count = prop.multiProcessorCount;
+        if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = 10; break; }
+        if (hipEventCreate(&d->ev0) != hipSuccess || hipEventCreate(&d->ev1) != hipSuccess) { set_error("hipEventCreate failed"); rc = 10; break; }
+        if (hipMalloc((void **) &d->counters, sizeof(unsigned long long) * MC_NCOUNTERS) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
+        if (params->algo == ACG_LDPC_QPADMM) {
+            d->name = "QP-ADMM";  // qp_admm.h:189
+            std::string err;
+            d->admm = admm_device_create(d->c, d->p, d->cu_count, err);
+            if (!d->admm) { set_error(err); rc = 3; break; }
+        } else if (params->algo == ACG_LDPC_BP_SUMPRODUCT || params->algo == ACG_LDPC_BP_MINSUM) {
+            d->name = params->algo == ACG_LDPC_BP_SUMPRODUCT ? "BP" : "MS";  // bp.h:218
+            rc = decoder_setup_bp(d);
+        } else {
+            set_error("unknown algo");
+            rc = 1;
+        }
+    } while (0);
+    if (rc) {
+        acg_ldpc_decoder_destroy(d);
+        return rc;
+    }
+    *out = d;
+    return 0;
+}
+
+void acg_ldpc_decoder_destroy(acg_ldpc_decoder *d) {
+    if (!d) return;
+    (void) hipSetDevice(d->device);
+    if (d->stream) (void) hipStreamSynchronize(d->stream);
+    for (void *p : d->dev_allocs) (void) hipFree(p);
+    if (d->admm) admm_device_destroy(d->admm);
+    if (d->st_y) (void) hipFree(d->st_y);
+    if (d->st_bits) (void) hipFree(d->st_bits);
+    if (d->st_ok) (void) hipFree(d->st_ok);
+    if (d->st_iters) (void) hipFree(d->st_iters);
+    if (d->cw_dev) (void) hipFree(d->cw_dev);
+    if (d->counters) (void) hipFree(d->counters);
+    if (d->ev0) (void) hipEventDestroy(d->ev0);
+    if (d->ev1) (void) hipEventDestroy(d->ev1);
+    if (d->stream) (void) hipStreamDestroy(d->stream);
+    delete d;
+}
+
+const char *acg_ldpc_decoder_name(const acg_ldpc_decoder *d) { return d->name.c_str(); }
+
+void acg_ldpc_decoder_layout(const acg_ldpc_decoder *d, int32_t *lds_bytes_per_frame, int32_t *lanes_per_frame,
+                             int32_t *frames_per_block, int32_t *grid_blocks) {
+    if (d->admm) {
+        admm_device_layout(d->admm, lds_bytes_per_frame, lanes_per_frame, frames_per_block, grid_blocks);
+        return;
+    }
+    if (lds_bytes_per_frame) *lds_bytes_per_frame = d->tab.lds_bytes_per_frame;
+    if (lanes_per_frame) *lanes_per_frame = d->L;
+    if (frames_per_block) *frames_per_block = d->frames_per_block;
+    if (grid_blocks) *grid_blocks = d->grid_cap;
+}
+
+static void fill_channel(DecodeArgs &a, double snr) {
+    const double var = std::pow(10, -(snr / 10)) / 2;  // llr_variance, channel.h:12
+    a.var = var;
+    a.inv_var2 = 2.0 / var;
+    a.sigma = (float) std::sqrt(var);
+}
+
+// launch on stream s (events recorded around the kernel on that stream)
+static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
+    a.max_iter = d->p.max_iter;
+    a.early_exit = d->p.early_exit;
+    a.ms_scale = (float) d->p.ms_scale;
+    if (a.frames <= 0) return 0;
+    HIP_OK(hipEventRecord(d->ev0, s));
+    if (d->admm) {
+        std::string err;
+        hipError_t e = admm_launch(d->admm, a, s, err);
+        if (e != hipSuccess) {
+            set_error(err.empty() ? std::string("admm launch: ") + hipGetErrorString(e) : err);
+            return 10;
+        }
+    } else {
+        int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
+        int grid = (int) std::min<int64_t>(blocks, d->grid_cap);
+        const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
+        HIP_OK(bp_launch(algo, d->f64, d->maxd, d->L, d->tab, a, grid, d->block, d->lds_block, s));
+    }
+    HIP_OK(hipEventRecord(d->ev1, s));
+    d->ev_valid = true;
+    return 0;
+}
+
+int acg_ldpc_decode_batch_dev(acg_ldpc_decoder *d, const void *y_dev, int32_t y_is_f64, int64_t frames, double snr,
+                              uint32_t *bits_dev, uint8_t *ok_dev, int32_t *iters_dev, void *stream) {
+    if (!d) {
+        set_error("null decoder");
+        return 1;
+    }
+    if (frames < 0 || (frames > 0 && !y_dev)) {
+        set_error("bad frames / y");
+        return 1;
+    }
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_OK(hipSetDevice(d->device));
+    DecodeArgs a{};
+    a.y = y_dev;
+    a.y_is_f64 = y_is_f64;
+    a.frames = frames;
+    fill_channel(a, snr);
+    a.out_bits = bits_dev;
+    a.out_ok = ok_dev;
+    a.out_iters = iters_dev;
+    a.mc = 0;
+    return launch_decode(d, a, stream ? (hipStream_t) stream : d->stream);
+}
+
+static int ensure_staging(acg_ldpc_decoder *d, int64_t frames) {
+    if (frames <= d->st_frames) return 0;
+    if (d->st_y) (void) hipFree(d->st_y);
+    if (d->st_bits) (void) hipFree(d->st_bits);
+    if (d->st_ok) (void) hipFree(d->st_ok);
+    if (d->st_iters) (void) hipFree(d->st_iters);
+    d->st_y = nullptr;
+    d->st_bits = nullptr;
+    d->st_ok = nullptr;
+    d->st_iters = nullptr;
+    d->st_frames = 0;
+    const int nwords = (d->c.n + 31) / 32;
+    HIP_OK(hipMalloc(&d->st_y, (size_t) frames * d->c.n * sizeof(double)));
+    HIP_OK(hipMalloc((void **) &d->st_bits, (size_t) frames * nwords * sizeof(uint32_t)));
+    HIP_OK(hipMalloc((void **) &d->st_ok, (size_t) frames));
+    HIP_OK(hipMalloc((void **) &d->st_iters, (size_t) frames * sizeof(int32_t)));
+    d->st_frames = frames;
+    return 0;
+}
+
+int acg_ldpc_decode_batch(acg_ldpc_decoder *d, const double *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
+                          int32_t *iters) {
+    if (!d) {
+        set_error("null decoder");
+        return 1;
+    }
+    if (frames < 0 || (frames > 0 && (!y || !bits || !ok))) {
+        set_error("null buffer");
+        return 1;
+    }
+    if (frames == 0) return 0;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_OK(hipSetDevice(d->device));
+    const int n = d->c.n, nwords = (n + 31) / 32;
+    // bounded chunks keep the staging buffers small for huge host batches
+    const int64_t chunk_max = 1 << 18;
+    std::vector<uint32_t> hbits;
+    for (int64_t f0 = 0; f0 < frames; f0 += chunk_max) {
+        const int64_t fc = std::min(chunk_max, frames - f0);
+        if (int rc = ensure_staging(d, fc)) return rc;
+        HIP_OK(hipMemcpyAsync(d->st_y, y + (size_t) f0 * n, (size_t) fc * n * sizeof(double), hipMemcpyHostToDevice, d->stream));
+        DecodeArgs a{};
+        a.y = d->st_y;
+        a.y_is_f64 = 1;
+        a.frames = fc;
+        fill_channel(a, snr);
+        a.out_bits = d->st_bits;
+        a.out_ok = d->st_ok;
+        a.out_iters = d->st_iters;
+        if (int rc = launch_decode(d, a, d->stream)) return rc;
+        hbits.resize((size_t) fc * nwords);
+        HIP_OK(hipMemcpyAsync(hbits.data(), d->st_bits, hbits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+        HIP_OK(hipMemcpyAsync(ok + f0, d->st_ok, (size_t) fc, hipMemcpyDeviceToHost, d->stream));
+        if (iters) HIP_OK(hipMemcpyAsync(iters + f0, d->st_iters, (size_t) fc * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+        HIP_OK(hipStreamSynchronize(d->stream));
+        for (int64_t f = 0; f < fc; f++) {
+            uint8_t *b = bits + (size_t) (f0 + f) * n;
+            const uint32_t *w = &hbits[(size_t) f * nwords];
+            for (int v = 0; v < n; v++) b[v] = (w[v >> 5] >> (v & 31)) & 1u;
+        }
+    }
+    return 0;
+}
+
+int acg_ldpc_decoder_sync(acg_ldpc_decoder *d) {
+    if (!d) return 1;
+    HIP_OK(hipSetDevice(d->device));
+    HIP_OK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+float acg_ldpc_decoder_last_kernel_ms(acg_ldpc_decoder *d) {
+    if (!d || !d->ev_valid) return -1.0f;
+    (void) hipSetDevice(d->device);
+    if (hipEventSynchronize(d->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, d->ev0, d->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ---------------------------------------------------------------- Monte-Carlo
+static int ensure_codewords(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg) {
+    if (!cfg->codewords || cfg->n_codewords <= 0) return 0;
+    if (d->cw_dev && d->cw_host_key == cfg->codewords && d->cw_count == cfg->n_codewords) return 0;
+    if (d->cw_dev) (void) hipFree(d->cw_dev);
+    d->cw_dev = nullptr;
+    const int n = d->c.n, nwords = (n + 31) / 32;
+    std::vector<uint32_t> packed((size_t) cfg->n_codewords * nwords, 0u);
+    for (int64_t f = 0; f < cfg->n_codewords; f++)
+        for (int v = 0; v < n; v++)
+            if (cfg->codewords[(size_t) f * n + v]) packed[(size_t) f * nwords + (v >> 5)] |= 1u << (v & 31);
+    HIP_OK(hipMalloc((void **) &d->cw_dev, packed.size() * sizeof(uint32_t)));
+    HIP_OK(hipMemcpy(d->cw_dev, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    d->cw_host_key = cfg->codewords;
+    d->cw_count = cfg->n_codewords;
+    return 0;
+}
+
+void acg_ldpc_mc_merge(acg_ldpc_mc_result *a, const acg_ldpc_mc_result *b) {
+    // merge_exp_results, experiment.h:70-78
+    a->correct += b->correct;
+    a->pseudo += b->pseudo;
+    a->total += b->total;
+    a->sum_hamming += b->sum_hamming;
+    a->sum_hamming_ok += b->sum_hamming_ok;
+    a->sum_hamming_wrong += b->sum_hamming_wrong;
+    a->sum_iters += b->sum_iters;
+    a->time_sec += b->time_sec;
+    a->kernel_ms += b->kernel_ms;
+}
+
+static int mc_run_host_noise(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc_result *res) {
+    // Bit-exact experiment.h:80-123 (single-threaded order): frame g (0-based global index) is
+    // seeded mt19937(g+1) (:90-97), transmitted with libstdc++ normal_distribution (channel.h:18-26),
+    // decoded on the device, classified on the host.
+    const int n = d->c.n;
+    const int64_t chunk_max = 1 << 16;
+    std::vector<double> y;
+    std::vector<uint8_t> bits, ok;
+    std::vector<int32_t> iters;
+    const double sigma = std::sqrt(std::pow(10, -(cfg->snr / 10)) / 2);
+    for (int64_t f0 = 0; f0 < cfg->frames; f0 += chunk_max) {
+        const int64_t fc = std::min(chunk_max, cfg->frames - f0);
+        y.resize((size_t) fc * n);
+        bits.resize((size_t) fc * n);
+        ok.resize((size_t) fc);
+        iters.resize((size_t) fc);
+        for (int64_t f = 0; f < fc; f++) {
+            const int64_t gidx = cfg->first_frame + f0 + f;
+            const uint8_t *cw = cfg->codewords ? cfg->codewords + (size_t) (gidx % cfg->n_codewords) * n : nullptr;
+            std::mt19937 rnd((uint32_t) (gidx + 1));
+            std::normal_distribution<double> dst(0, sigma);
+            for (int i = 0; i < n; i++) y[(size_t) f * n + i] = ((cw && cw[i]) ? -1.0 : 1.0) + dst(rnd);
+        }
+        if (int rc = acg_ldpc_decode_batch(d, y.data(), fc, cfg->snr, bits.data(), ok.data(), iters.data())) return rc;
+        res->kernel_ms += acg_ldpc_decoder_last_kernel_ms(d);
+        for (int64_t f = 0; f < fc; f++) {
+            const int64_t gidx = cfg->first_frame + f0 + f;
+            const uint8_t *cw = cfg->codewords ? cfg->codewords + (size_t) (gidx % cfg->n_codewords) * n : nullptr;
+            const uint8_t *b = &bits[(size_t) f * n];
+            bool is_correct = false;
+            if (ok[f] && code_is_codeword(d->c, b)) {  // experiment.h:110-111
+                bool eq = true;
+                for (int i = 0; i < n; i++) eq &= (b[i] == (cw ? cw[i] : 0));
+                if (eq) {
+                    res->correct++;
+                    is_correct = true;
+                } else
+                    res->pseudo++;
+            }
+            res->total++;
+            int h = 0;
+            for (int i = 0; i < n; i++) {
+                const bool c1 = cw && cw[i];
+                const double yv = y[(size_t) f * n + i];
+                if (!c1 && yv <= 0) h++;
+                if (c1 && yv > 0) h++;
+            }
+            res->sum_hamming += h;
+            if (is_correct) res->sum_hamming_ok += h;
+            else res->sum_hamming_wrong += h;
+            res->sum_iters += iters[f];
+        }
+    }
+    return 0;
+}
+
+int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc_result *res) {
+    if (!d || !cfg || !res) {
+        set_error("null argument");
+        return 1;
+    }
+    if (cfg->frames < 0 || (cfg->codewords && cfg->n_codewords <= 0)) {
+        set_error("bad mc cfg");
+        return 1;
+    }
+    std::memset(res, 0, sizeof(*res));
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = 0;
+    if (cfg->noise == ACG_LDPC_NOISE_HOST_MT19937) {
+        rc = mc_run_host_noise(d, cfg, res);
+    } else {
+        std::lock_guard<std::mutex> lk(d->mu);
+        HIP_OK(hipSetDevice(d->device));
+        if ((rc = ensure_codewords(d, cfg))) return rc;
+        HIP_OK(hipMemsetAsync(d->counters, 0, sizeof(unsigned long long) * MC_NCOUNTERS, d->stream));
+        DecodeArgs a{};
+        a.frames = cfg->frames;
+        fill_channel(a, cfg->snr);
+        a.mc = 1;
+        a.seed = cfg->seed;
+        a.first_frame = cfg->first_frame;
+        a.cw_packed = cfg->codewords ? d->cw_dev : nullptr;
+        a.n_cw = cfg->codewords ? cfg->n_codewords : 1;
+        a.counters = d->counters;
+        if ((rc = launch_decode(d, a, d->stream))) return rc;
+        unsigned long long h[MC_NCOUNTERS];
+        HIP_OK(hipMemcpyAsync(h, d->counters, sizeof(h), hipMemcpyDeviceToHost, d->stream));
+        HIP_OK(hipStreamSynchronize(d->stream));
+        res->correct = (int64_t) h[MC_CORRECT];
+        res->pseudo = (int64_t) h[MC_PSEUDO];
+        res->total = (int64_t) h[MC_TOTAL];
+        res->sum_hamming = (int64_t) h[MC_HAM];
+        res->sum_hamming_ok = (int64_t) h[MC_HAM_OK];
+        res->sum_hamming_wrong = (int64_t) h[MC_HAM_WRONG];
+        res->sum_iters = (int64_t) h[MC_ITERS];
+        float ms = 0;
+        if (cfg->frames > 0 && hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) res->kernel_ms = ms;
+    }
+    res->time_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int acg_ldpc_awgn_dev(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, float *y_dev, void *stream) {
+    if (!d || !cfg || !y_dev) {
+        set_error("null argument");
+        return 1;
+    }
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_OK(hipSetDevice(d->device));
+    if (int rc = ensure_codewords(d, cfg)) return rc;
+    const double var = std::pow(10, -(cfg->snr / 10)) / 2;
+    HIP_OK(awgn_launch(y_dev, cfg->frames, d->c.n, (d->c.n + 31) / 32, cfg->first_frame, cfg->seed,
+                       cfg->codewords ? d->cw_dev : nullptr, cfg->codewords ? cfg->n_codewords : 1,
+                       (float) std::sqrt(var), stream ? (hipStream_t) stream : d->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------- host generators
+int acg_ldpc_gen_codewords(const uint8_t *G, int32_t k, int32_t n, uint32_t seed, int64_t count, uint8_t *out) {
+    if (!G || !out || k <= 0 || n <= 0 || count < 0) {
+        set_error("bad argument");
+        return 1;
+    }
+    std::mt19937 rnd(seed);  // main.cpp:63
+    for (int64_t f = 0; f < count; f++) {
+        uint8_t *res = out + (size_t) f * n;
+        std::memset(res, 0, (size_t) n);
+        for (int i = 0; i < k; i++)
+            if (rnd() % 2 == 0) {  // channel.h:33
+                const uint8_t *row = G + (size_t) i * n;
+                for (int j = 0; j < n; j++) res[j] ^= (row[j] ? 1 : 0);
+            }
+    }
+    return 0;
+}
+
+double acg_ldpc_llr_variance(double snr) { return std::pow(10, -(snr / 10)) / 2; }
+
+int acg_ldpc_transmit_host(const uint8_t *codewords, int64_t n_codewords, int32_t n, int64_t first_frame,
+                           int64_t frames, double snr, double *y) {
+    if (!y || n <= 0 || frames < 0 || (codewords && n_codewords <= 0)) {
+        set_error("bad argument");
+        return 1;
+    }
+    const double sigma = std::sqrt(acg_ldpc_llr_variance(snr));  // channel.h:20
+    for (int64_t f = 0; f < frames; f++) {
+        const int64_t gidx = first_frame + f;
+        const uint8_t *cw = codewords ? codewords + (size_t) (gidx % n_codewords) * n : nullptr;
+        std::mt19937 rnd((uint32_t) (gidx + 1));              // experiment.h:90-97, single-threaded order
+        std::normal_distribution<double> dst(0, sigma);       // channel.h:22
+        for (int i = 0; i < n; i++) y[(size_t) f * n + i] = ((cw && cw[i]) ? -1.0 : 1.0) + dst(rnd);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- debug helpers (tests only)
+int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f64) {
+    const size_t es = f64 ? 8 : 4;
+    void *dx = nullptr, *dout = nullptr;
+    HIP_OK(hipMalloc(&dx, es * n));
+    HIP_OK(hipMalloc(&dout, es * n));
+    HIP_OK(hipMemcpy(dx, x_host, es * n, hipMemcpyHostToDevice));
+    HIP_OK(phi_debug_launch(dx, dout, n, f64, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out_host, dout, es * n, hipMemcpyDeviceToHost));
+    (void) hipFree(dx);
+    (void) hipFree(dout);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+// Host-side code analysis: parity-matrix text format, Tanner-graph CSR, the LDS message layout
+// used by the fused BP kernels, the QP-ADMM constraint groups, and the GF(2) helpers the
+// Monte-Carlo callers need.  Plain C++ (no HIP).  Runs once per H — the reference redoes the
+// equivalent work for every frame (bp.h:136-153, qp_admm.h:13-102).
+#include "ldpc_internal.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+namespace acg {
+
+// ---------------------------------------------------------------- text format
+// Same observable behaviour as read_pcm (utils/parse_data.h:6-25): whitespace-separated row
+// tokens; inside a token every ',' closes a cell whose value is decided by the last non-','
+// character before it ('1' -> 1, anything else -> 0); a missing trailing ',' is implied.
+bool code_read_txt(const char *path, std::vector<uint8_t> &H, int &m, int &n) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) {
+        set_error(std::string("cannot open ") + path);
+        return false;
+    }
+    std::vector<char> buf;
+    {
+        char tmp[1 << 16];
+        size_t got;
+        while ((got = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+    }
+    std::fclose(f);
+    H.clear();
+    m = 0;
+    n = -1;
+    bool cell = false;  // carries across rows exactly like the reference's `bool t`
+    size_t i = 0, N = buf.size();
+    auto is_ws = [](char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
+    while (i < N) {
+        while (i < N && is_ws(buf[i])) i++;
+        if (i >= N) break;
+        int cols = 0;
+        char last = 0;
+        while (i < N && !is_ws(buf[i])) {
+            last = buf[i];
+            if (last == ',') {
+                H.push_back(cell ? 1 : 0);
+                cols++;
+            } else {
+                cell = (last == '1');
+            }
+            i++;
+        }
+        if (last != ',') {
+            H.push_back(cell ? 1 : 0);
+            cols++;
+        }
+        if (n < 0) n = cols;
+        else if (cols != n) {
+            set_error(std::string("ragged parity matrix in ") + path);
+            return false;
+        }
+        m++;
+    }
+    if (m == 0 || n <= 0) {
+        set_error(std::string("empty parity matrix in ") + path);
+        return false;
+    }
+    return true;
+}
+
+// save_matrix (utils/parse_data.h:44-54): "0,1,...,1\n" per row, no trailing comma
+bool code_write_txt(const Code &c, const char *path) {
+    FILE *f = std::fopen(path, "wb");
+    if (!f) {
+        set_error(std::string("cannot open for writing ") + path);
+        return false;
+    }
+    std::string line;
+    for (int i = 0; i < c.m; i++) {
+        line.clear();
+        for (int j = 0; j < c.n; j++) {
+            line.push_back(c.H[(size_t) i * c.n + j] ? '1' : '0');
+            if (j != c.n - 1) line.push_back(',');
+        }
+        line.push_back('\n');
+        std::fwrite(line.data(), 1, line.size(), f);
+    }
+    std::fclose(f);
+    return true;
+}
+
+// ---------------------------------------------------------------- graph
+bool code_build(Code &c, const uint8_t *H, int m, int n) {
+    if (m <= 0 || n <= 0) {
+        set_error("parity matrix must have m > 0 and n > 0");
+        return false;
+    }
+    c.m = m;
+    c.n = n;
+    c.H.assign((size_t) m * n, 0);
+    for (size_t i = 0; i < (size_t) m * n; i++) c.H[i] = H[i] ? 1 : 0;
+    c.row_ptr.assign(m + 1, 0);
+    c.col_ptr.assign(n + 1, 0);
+    c.edge_var.clear();
+    for (int i = 0; i < m; i++) {
+        c.row_ptr[i] = (int) c.edge_var.size();
+        for (int j = 0; j < n; j++)
+            if (c.H[(size_t) i * n + j]) {
+                c.edge_var.push_back(j);
+                c.col_ptr[j + 1]++;
+            }
+    }
+    c.E = (int) c.edge_var.size();
+    c.row_ptr[m] = c.E;
+    for (int j = 0; j < n; j++) c.col_ptr[j + 1] += c.col_ptr[j];
+    c.col_edge.assign(c.E, 0);
+    std::vector<int> fill(n, 0);
+    for (int e = 0; e < c.E; e++) {
+        int v = c.edge_var[e];
+        c.col_edge[c.col_ptr[v] + fill[v]++] = e;
+    }
+    c.max_cdeg = c.max_vdeg = 0;
+    for (int i = 0; i < m; i++) c.max_cdeg = std::max(c.max_cdeg, c.row_ptr[i + 1] - c.row_ptr[i]);
+    for (int j = 0; j < n; j++) c.max_vdeg = std::max(c.max_vdeg, c.col_ptr[j + 1] - c.col_ptr[j]);
+    admm_layout_build(c);
+    return true;
+}
+
+bool code_is_codeword(const Code &c, const uint8_t *bits) {
+    for (int i = 0; i < c.m; i++) {
+        int s = 0;
+        for (int e = c.row_ptr[i]; e < c.row_ptr[i + 1]; e++) s ^= (bits[c.edge_var[e]] & 1);
+        if (s) return false;
+    }
+    return true;
+}
+
+// GetOrtogonal (utils/codeword.h:97-128) on 64-bit packed rows: for row i the pivot is its first
+// non-zero column; the row is XORed into every other row holding that column; non-pivot column j
+// yields generator row e_j + sum_i H'[i][j] e_pos(i).
+bool code_generator(const Code &c, uint8_t *G) {
+    const int m = c.m, n = c.n, W = (n + 63) / 64;
+    std::vector<uint64_t> R((size_t) m * W, 0);
+    for (int i = 0; i < m; i++)
+        for (int e = c.row_ptr[i]; e < c.row_ptr[i + 1]; e++) {
+            int j = c.edge_var[e];
+            R[(size_t) i * W + (j >> 6)] |= 1ull << (j & 63);
+        }
+    std::vector<int> pos(m, -1);
+    std::vector<uint8_t> is_main(n, 0);
+    for (int i = 0; i < m; i++) {
+        const uint64_t *ri = &R[(size_t) i * W];
+        for (int w = 0; w < W; w++)
+            if (ri[w]) {
+                pos[i] = w * 64 + __builtin_ctzll(ri[w]);
+                break;
+            }
+        if (pos[i] < 0) return false;
+        const int pw = pos[i] >> 6;
+        const uint64_t pb = 1ull << (pos[i] & 63);
+        for (int k = 0; k < m; k++)
+            if (k != i && (R[(size_t) k * W + pw] & pb)) {
+                uint64_t *rk = &R[(size_t) k * W];
+                for (int w = 0; w < W; w++) rk[w] ^= ri[w];
+            }
+        is_main[pos[i]] = 1;
+    }
+    std::memset(G, 0, (size_t) (n - m) * n);
+    int idx = 0;
+    for (int j = 0; j < n; j++)
+        if (!is_main[j]) {
+            G[(size_t) idx * n + j] = 1;
+            for (int i = 0; i < m; i++)
+                if (R[(size_t) i * W + (j >> 6)] >> (j & 63) & 1) G[(size_t) idx * n + pos[i]] = 1;
+            idx++;
+        }
+    return true;
+}
+
+// ---------------------------------------------------------------- BP LDS layout
+bool bp_layout_build(const Code &c, int L, BpLayout &o) {
+    o = BpLayout();
+    o.L = L;
+    o.max_cdeg = c.max_cdeg;
+    o.max_vdeg = c.max_vdeg;
+    const int m = c.m, n = c.n;
+    std::vector<int> corder(m), vorder(n);
+    std::iota(corder.begin(), corder.end(), 0);
+    std::iota(vorder.begin(), vorder.end(), 0);
+    auto cdeg = [&](int i) { return c.row_ptr[i + 1] - c.row_ptr[i]; };
+    auto vdeg = [&](int j) { return c.col_ptr[j + 1] - c.col_ptr[j]; };
+    std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return cdeg(a) > cdeg(b); });
+    std::stable_sort(vorder.begin(), vorder.end(), [&](int a, int b) { return vdeg(a) > vdeg(b); });
+
+    o.n_cpass = (m + L - 1) / L;
+    o.n_vpass = (n + L - 1) / L;
+    o.c_chk.assign((size_t) o.n_cpass * L, -1);
+    o.v_var.assign((size_t) o.n_vpass * L, -1);
+    for (int s = 0; s < m; s++) o.c_chk[s] = corder[s];
+    for (int s = 0; s < n; s++) o.v_var[s] = vorder[s];
+    o.c_cnt_ge.assign(c.max_cdeg + 2, 0);
+    o.v_cnt_ge.assign(c.max_vdeg + 2, 0);
+    for (int i = 0; i < m; i++)
+        for (int d = 0; d <= cdeg(i); d++) o.c_cnt_ge[d]++;
+    for (int j = 0; j < n; j++)
+        for (int d = 0; d <= vdeg(j); d++) o.v_cnt_ge[d]++;
+
+    // A layout
+    std::vector<int> edge_pos(c.E, -1);
+    int off = 0;
+    o.c_maxdeg.resize(o.n_cpass);
+    o.c_off.resize(o.n_cpass);
+    for (int p = 0; p < o.n_cpass; p++) {
+        int md = cdeg(corder[(size_t) p * L]);  // sorted descending: first slot of the pass is the max
+        o.c_maxdeg[p] = md;
+        o.c_off[p] = off;
+        for (int l = 0; l < L; l++) {
+            int s = p * L + l;
+            if (s >= m) break;
+            int chk = corder[s];
+            for (int j = 0; j < cdeg(chk); j++) edge_pos[c.row_ptr[chk] + j] = off + j * L + l;
+        }
+        off += md * L;
+    }
+    o.zero_pos = off;
+    o.a_words = (off + 1 + 3) & ~3;
+    if (o.a_words > 65535) {
+        set_error("code too large for the fused LDS kernels (message words per frame exceed 65535)");
+        return false;
+    }
+    // variable-side index table
+    o.v_maxdeg.resize(o.n_vpass);
+    o.v_idx_off.resize(o.n_vpass);
+    int ioff = 0;
+    for (int p = 0; p < o.n_vpass; p++) {
+        int md = vdeg(vorder[(size_t) p * L]);
+        o.v_maxdeg[p] = md;
+        o.v_idx_off[p] = ioff;
+        ioff += md * L;
+    }
+    o.v_apos_len = ioff;
+    o.v_apos.assign((size_t) std::max(ioff, 1), (uint16_t) o.zero_pos);
+    for (int p = 0; p < o.n_vpass; p++)
+        for (int l = 0; l < L; l++) {
+            int s = p * L + l;
+            if (s >= n) break;
+            int v = vorder[s];
+            for (int k = 0; k < vdeg(v); k++)
+                o.v_apos[(size_t) o.v_idx_off[p] + (size_t) k * L + l] = (uint16_t) edge_pos[c.col_edge[c.col_ptr[v] + k]];
+        }
+    return true;
+}
+
+// ---------------------------------------------------------------- QP-ADMM groups
+// ConstructADMMProblem (qp_admm.h:13-102): a check of degree d >= 3 becomes the chain
+// (x1,x2,a1),(a1,x3,a2),...,(a_{d-3},x_{d-1},x_d) with auxiliaries numbered from n upward in row
+// order (:84-91); each triple contributes rows (+,-,-)<=0, (-,+,-)<=0, (-,-,+)<=0, (+,+,+)<=2.
+void admm_layout_build(Code &c) {
+    AdmmLayout &a = c.admm;
+    a = AdmmLayout();
+    a.n = c.n;
+    int pos = c.n;
+    auto add_group = [&](int type, int v0, int v1, int v2) {
+        a.grp_type.push_back((uint8_t) type);
+        a.grp_var.push_back(v0);
+        a.grp_var.push_back(v1);
+        a.grp_var.push_back(v2);
+        a.n_con += (type == 3) ? 4 : type;
+        a.nnz += (type == 3) ? 12 : (type == 2 ? 4 : 1);
+    };
+    for (int i = 0; i < c.m; i++) {
+        const int *idx = &c.edge_var[c.row_ptr[i]];
+        int d = c.row_ptr[i + 1] - c.row_ptr[i];
+        if (d == 0) continue;
+        if (d == 1) {
+            add_group(1, idx[0], -1, -1);
+            continue;
+        }
+        if (d == 2) {
+            add_group(2, idx[0], idx[1], -1);
+            continue;
+        }
+        int last = idx[0];
+        for (int j = 1; j < d - 2; j++) {
+            int aux = pos++;
+            add_group(3, last, idx[j], aux);
+            last = aux;
+        }
+        add_group(3, last, idx[d - 2], idx[d - 1]);
+    }
+    a.n_var = pos;
+    a.n_grp = (int) a.grp_type.size();
+    a.e.assign(a.n_var, 0.0);
+    a.var_ptr.assign(a.n_var + 1, 0);
+    for (int g = 0; g < a.n_grp; g++) {
+        int t = a.grp_type[g];
+        for (int w = 0; w < t; w++) {
+            int v = a.grp_var[(size_t) g * 3 + w];
+            a.var_ptr[v + 1]++;
+            a.e[v] += (t == 3) ? 4.0 : (t == 2 ? 2.0 : 1.0);
+        }
+    }
+    for (int v = 0; v < a.n_var; v++) a.var_ptr[v + 1] += a.var_ptr[v];
+    a.var_grp.assign(a.var_ptr[a.n_var], 0);
+    std::vector<int> fill(a.n_var, 0);
+    for (int g = 0; g < a.n_grp; g++) {
+        int t = a.grp_type[g];
+        for (int w = 0; w < t; w++) {
+            int v = a.grp_var[(size_t) g * 3 + w];
+            a.var_grp[a.var_ptr[v] + fill[v]++] = g * 4 + w;
+        }
+    }
+    a.e_min = 1e300;
+    a.e_max = -1e300;
+    for (int v = 0; v < a.n_var; v++) {
+        a.e_min = std::min(a.e_min, a.e[v]);
+        a.e_max = std::max(a.e_max, a.e[v]);
+    }
+    if (a.n_var == 0) a.e_min = a.e_max = 0;
+}
+
+}  // namespace acg

@@ -1,0 +1,64 @@
+// Device-facing argument blocks shared by the .hip kernels and the host API.  Not part of the ABI.
+#pragma once
+
+#include <cstdint>
+
+namespace acg {
+
+// Device copies of BpLayout (see ldpc_internal.hpp for the meaning of each table).
+struct BpTables {
+    const int32_t *c_maxdeg;
+    const int32_t *c_off;
+    const int32_t *c_cnt_ge;
+    const int32_t *v_maxdeg;
+    const int32_t *v_idx_off;
+    const int32_t *v_cnt_ge;
+    const int32_t *v_var;
+    const uint16_t *v_apos;
+    int32_t n_cpass, n_vpass;
+    int32_t a_words, zero_pos;
+    int32_t m, n, nwords;      // nwords = (n+31)/32 packed output words per frame
+    int32_t llr_words;         // n_vpass * L
+    int32_t lds_bytes_per_frame;
+};
+
+// per-launch MC statistics (one row per launch; experiment.h:25-68)
+enum { MC_CORRECT = 0, MC_PSEUDO, MC_TOTAL, MC_HAM, MC_HAM_OK, MC_HAM_WRONG, MC_ITERS, MC_NCOUNTERS };
+
+struct DecodeArgs {
+    // input
+    const void *y;      // frames*n float or double (null in MC/device-noise mode)
+    int32_t y_is_f64;
+    int64_t frames;
+    double inv_var2;    // 2 / sigma^2  (llr = y * inv_var2; fp64 path divides exactly like channel.h:14-16)
+    double var;         // sigma^2
+    // output (any may be null in MC mode)
+    uint32_t *out_bits;
+    uint8_t *out_ok;
+    int32_t *out_iters;
+    // params
+    int32_t max_iter;
+    int32_t early_exit;
+    float ms_scale;
+    // Monte-Carlo mode
+    int32_t mc;          // 0 = decode y; 1 = generate y on device + classify
+    uint64_t seed;
+    int64_t first_frame;
+    const uint32_t *cw_packed;  // n_cw * nwords, null = all-zero codeword
+    int64_t n_cw;
+    float sigma;
+    unsigned long long *counters;  // MC_NCOUNTERS
+};
+
+struct AdmmTables {
+    const int32_t *grp_var;   // [n_grp_pad*3] laid out [w][slot]: variable ids (or -1)
+    const uint8_t *grp_type;  // [n_grp_pad]
+    const int32_t *var_ptr;   // [n_var_pad+1]... see admm_kernels.hip
+    const int32_t *var_grp;
+    const double *inv_coef;   // filled per decoder (depends on alpha, mu)
+    int32_t n, n_var, n_grp, n_gpass, n_vpass, max_vlist;
+    int32_t nwords;
+    int32_t lds_bytes_per_frame;
+};
+
+}  // namespace acg

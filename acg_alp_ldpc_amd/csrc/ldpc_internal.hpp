@@ -1,0 +1,73 @@
+// Internal host-side structures shared by code.cpp (graph analysis, no HIP) and the HIP
+// translation units.  Not part of the ABI.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace acg {
+
+void set_error(const std::string &msg);
+
+// Layout of one frame's message state for a given number of cooperating lanes L.
+//
+// Check side ("A layout"): checks sorted by degree (descending, stable), dealt L per pass.
+// The j-th edge (variables ascending, the order of bp.h:144-147) of the check in slot (p, l)
+// lives at word  c_off[p] + j*L + l : every check-phase access is a unit-stride, bank-conflict
+// free LDS access with no index table.  Slots j >= degree are padding and hold +0.0 forever
+// (neutral for the phi-sum, the sign product and the syndrome bit).
+//
+// Variable side: variables sorted by degree (descending, stable), L per pass.  The k-th edge
+// (checks ascending) of the variable in slot (p, l) is found through v_apos[v_idx_off[p] + k*L + l],
+// the A-layout word of that edge; padding entries point at `zero_pos`, a word that is always +0.0.
+// Messages are updated IN PLACE: a word holds v->c before the check phase and c->v after it.
+struct BpLayout {
+    int L = 0;
+    int n_cpass = 0, n_vpass = 0;
+    int a_words = 0;  // message words incl. the zero cell (rounded up to a multiple of 4)
+    int zero_pos = 0;
+    int max_cdeg = 0, max_vdeg = 0;
+    std::vector<int32_t> c_maxdeg, c_off;   // [n_cpass]
+    std::vector<int32_t> c_cnt_ge;          // [max_cdeg+2]: number of checks with degree >= d
+    std::vector<int32_t> c_chk;             // [n_cpass*L] check id per slot, -1 = none
+    std::vector<int32_t> v_maxdeg, v_idx_off;  // [n_vpass]
+    std::vector<int32_t> v_cnt_ge;          // [max_vdeg+2]
+    std::vector<int32_t> v_var;             // [n_vpass*L] variable id per slot, -1 = none
+    std::vector<uint16_t> v_apos;           // [sum_p v_maxdeg[p]*L]
+    int v_apos_len = 0;
+};
+
+// QP-ADMM problem structure (qp_admm.h:13-102) regrouped by "constraint group": one group per
+// three-variable check (4 rows, qp_admm.h:34-57), per degree-2 check (2 rows, :75-83) or per
+// degree-1 check (1 row, :70-74).  Rows of a group only touch the group's <=3 variables, so the
+// per-row state never leaves the lane that owns the group.
+struct AdmmLayout {
+    int n = 0, n_var = 0, n_con = 0, nnz = 0, n_grp = 0;
+    double e_min = 0, e_max = 0;
+    std::vector<int32_t> grp_var;   // [n_grp*3] variable ids (-1 = unused)
+    std::vector<uint8_t> grp_type;  // 3 / 2 / 1
+    std::vector<double> e;          // [n_var] = sum_j A_ji^2
+    // per variable: list of (group, position-in-group) in construction order
+    std::vector<int32_t> var_ptr;   // [n_var+1]
+    std::vector<int32_t> var_grp;   // [sum] group*4 + position
+};
+
+struct Code {
+    int m = 0, n = 0, E = 0;
+    std::vector<uint8_t> H;          // dense m*n
+    std::vector<int32_t> row_ptr, edge_var;   // CSR by check (variables ascending)
+    std::vector<int32_t> col_ptr, col_edge;   // CSR by variable (checks ascending) -> edge id
+    int max_cdeg = 0, max_vdeg = 0;
+    AdmmLayout admm;
+};
+
+bool code_build(Code &c, const uint8_t *H, int m, int n);
+bool code_read_txt(const char *path, std::vector<uint8_t> &H, int &m, int &n);
+bool code_write_txt(const Code &c, const char *path);
+bool code_generator(const Code &c, uint8_t *G);
+bool code_is_codeword(const Code &c, const uint8_t *bits);
+bool bp_layout_build(const Code &c, int L, BpLayout &out);
+void admm_layout_build(Code &c);
+
+}  // namespace acg

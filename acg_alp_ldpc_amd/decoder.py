@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's Decoder operator API (algo/algo.h:6-11).
+
+    BeliefPropagationDecoder(max_iter)                     algo/bp.h:208-222
+    QPADMMDecoder(alpha, mu, max_iter=2000, eps_stop=1e-5) algo/qp_admm.h:180-194
+    MinSumDecoder(max_iter, scale)                         build-added, not in the reference
+
+    decode(H, channel_word, snr) -> (codeword, ok)         same argument meaning as algo/algo.h:8:
+        H: m x n 0/1 matrix (or a ParityCheckMatrix), channel_word: n raw channel symbols y
+        (NOT LLRs), snr: Es/N0 in dB.  BP failure returns (empty array, False) like bp.h:198.
+    decode_batch(H, Y, snr) -> (bits[F,n], ok[F], iters[F])
+    name() -> "BP" / "QP-ADMM" / "MS"
+
+Every call runs on the GPU through libacg_ldpc_hip.so; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, check, lib
+from .code import ParityCheckMatrix
+
+
+class Decoder:
+    _algo = None
+
+    def __init__(self, max_iter, early_exit=True, precision=_lib.PREC_DEFAULT, device=-1, lanes_per_frame=0):
+        self.max_iter = int(max_iter)
+        self.early_exit = bool(early_exit)
+        self.precision = precision
+        self.device = device
+        self.lanes_per_frame = lanes_per_frame
+        self._handles = {}  # analysed-graph cache keyed on H (SURVEY §8b "Inputs")
+
+    # -- parameters -------------------------------------------------------------------------
+    def _params(self):
+        p = Params()
+        lib().acg_ldpc_params_default(C.byref(p))
+        p.algo = self._algo
+        p.max_iter = self.max_iter
+        p.early_exit = 1 if self.early_exit else 0
+        p.precision = self.precision
+        p.device = self.device
+        p.lanes_per_frame = self.lanes_per_frame
+        return p
+
+    # -- handle cache -----------------------------------------------------------------------
+    def _key(self, H):
+        if isinstance(H, ParityCheckMatrix):
+            return ("pcm", id(H))
+        a = np.ascontiguousarray(H, dtype=np.uint8)
+        return ("dense", a.shape, hash(a.tobytes()))
+
+    def handle(self, H):
+        k = self._key(H)
+        ent = self._handles.get(k)
+        if ent is None:
+            code = H if isinstance(H, ParityCheckMatrix) else ParityCheckMatrix(H)
+            h = C.c_void_p()
+            p = self._params()
+            check(lib().acg_ldpc_decoder_create(code._h, C.byref(p), C.byref(h)))
+            ent = (h, code)
+            self._handles[k] = ent
+        return ent
+
+    def close(self):
+        for h, _ in self._handles.values():
+            lib().acg_ldpc_decoder_destroy(h)
+        self._handles = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference API ----------------------------------------------------------------------
+    def name(self):
+        return {_lib.ALGO_BP: "BP", _lib.ALGO_QPADMM: "QP-ADMM", _lib.ALGO_MINSUM: "MS"}[self._algo]
+
+    def decode(self, H, channel_word, snr):
+        bits, ok, _ = self.decode_batch(H, np.asarray(channel_word, dtype=np.float64)[None, :], snr)
+        if not ok[0] and self._algo != _lib.ALGO_QPADMM:
+            return np.zeros(0, dtype=np.uint8), False  # {TCodeword(), false}, bp.h:198
+        return bits[0], bool(ok[0])
+
+    def decode_batch(self, H, Y, snr):
+        h, code = self.handle(H)
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        if Y.ndim != 2 or Y.shape[1] != code.n:
+            raise ValueError("Y must be frames x n")
+        F = Y.shape[0]
+        bits = np.zeros((F, code.n), dtype=np.uint8)
+        ok = np.zeros(F, dtype=np.uint8)
+        iters = np.zeros(F, dtype=np.int32)
+        check(lib().acg_ldpc_decode_batch(h, Y.ctypes.data, F, float(snr), bits.ctypes.data, ok.ctypes.data,
+                                          iters.ctypes.data))
+        return bits, ok, iters
+
+    def decode_batch_dev(self, H, y_ptr, y_is_f64, frames, snr, bits_ptr, ok_ptr, iters_ptr=None, stream=None):
+        """device pointers (ints); asynchronous on `stream` (None = the decoder's own stream)"""
+        h, _ = self.handle(H)
+        check(lib().acg_ldpc_decode_batch_dev(h, y_ptr, 1 if y_is_f64 else 0, int(frames), float(snr), bits_ptr,
+                                              ok_ptr, iters_ptr, stream))
+
+    def sync(self, H):
+        h, _ = self.handle(H)
+        check(lib().acg_ldpc_decoder_sync(h))
+
+    def last_kernel_ms(self, H):
+        h, _ = self.handle(H)
+        return float(lib().acg_ldpc_decoder_last_kernel_ms(h))
+
+    def layout(self, H):
+        h, _ = self.handle(H)
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        lib().acg_ldpc_decoder_layout(h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return dict(lds_bytes_per_frame=a.value, lanes_per_frame=b.value, frames_per_block=c.value,
+                    grid_blocks=d.value)
+
+
+class BeliefPropagationDecoder(Decoder):
+    """algo/bp.h:208-222 — flooding sum-product in the phi domain, early exit at the first zero syndrome."""
+    _algo = _lib.ALGO_BP
+
+    def __init__(self, max_iter, **kw):
+        super().__init__(max_iter, **kw)
+
+
+class MinSumDecoder(Decoder):
+    """Build-added normalised min-sum (north_star).  Not in the reference: parity unpinned."""
+    _algo = _lib.ALGO_MINSUM
+
+    def __init__(self, max_iter, scale=1.0, **kw):
+        super().__init__(max_iter, **kw)
+        self.scale = float(scale)
+
+    def _params(self):
+        p = super()._params()
+        p.ms_scale = self.scale
+        return p
+
+
+class QPADMMDecoder(Decoder):
+    """algo/qp_admm.h:180-194 (same defaults: max_iter=2000, eps_stop=1e-5)"""
+    _algo = _lib.ALGO_QPADMM
+
+    def __init__(self, alpha, mu, max_iter=2000, eps_stop=1e-5, **kw):
+        super().__init__(max_iter, **kw)
+        self.alpha, self.mu, self.eps_stop = float(alpha), float(mu), float(eps_stop)
+
+    def _params(self):
+        p = super()._params()
+        p.alpha, p.mu, p.eps_stop = self.alpha, self.mu, self.eps_stop
+        return p

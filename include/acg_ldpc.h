@@ -1,0 +1,187 @@
+/*
+ * acg_ldpc.h — C ABI of the MI355X-native batched LDPC decoder (libacg_ldpc_hip.so).
+ *
+ * Drop-in boundary for ONE path of GreatDrake/acg-alp-ldpc: the per-frame call
+ *     pair<TCodeword,bool> Decoder::decode(const TMatrix &H, const TFVector &y, double snr)
+ * (reference algo/algo.h:8) as implemented by BeliefPropagationDecoder (algo/bp.h:208-222) and
+ * QPADMMDecoder (algo/qp_admm.h:180-194), plus the Monte-Carlo loop that drives it
+ * (experiment.h:80-139) with its AWGN generator (utils/channel.h:18-26).
+ *
+ * Plain C: opaque handles, caller-owned buffers, int return codes (0 = ok), no exceptions,
+ * no torch / STL types.  Every entry point cites the reference interface it replaces.
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Threading: a decoder handle owns one HIP stream + workspace on one device; calls on the same
+ * handle are serialised by an internal mutex (the reference calls one decoder object from
+ * THREADS_NUM pthreads, experiment.h:101,127-130 — that keeps working, one handle per thread
+ * is faster).  Code handles are immutable after creation and may be shared.
+ */
+#ifndef ACG_LDPC_H
+#define ACG_LDPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct acg_ldpc_code acg_ldpc_code;       /* parity-check matrix + analysed Tanner graph (host) */
+typedef struct acg_ldpc_decoder acg_ldpc_decoder; /* device-resident graph, workspace, stream, params */
+
+/* algorithm selector */
+enum {
+    ACG_LDPC_BP_SUMPRODUCT = 0, /* algo/bp.h — the reference's BP (phi-domain sum-product) */
+    ACG_LDPC_BP_MINSUM = 1,     /* build-added (north_star); NOT in the reference: parity unpinned */
+    ACG_LDPC_QPADMM = 2         /* algo/qp_admm.h */
+};
+
+/* arithmetic selector */
+enum {
+    ACG_LDPC_PREC_DEFAULT = 0, /* BP: fp32 messages; QP-ADMM: fp64 */
+    ACG_LDPC_PREC_F64 = 1,     /* everything fp64 */
+    ACG_LDPC_PREC_F32 = 2      /* everything fp32 (QP-ADMM then matches FER only) */
+};
+
+/* noise source for acg_ldpc_mc_run */
+enum {
+    ACG_LDPC_NOISE_DEVICE_PHILOX = 0, /* counter-based, keyed on (seed, global frame, symbol): same
+                                         frames for any GPU count; statistically validated only */
+    ACG_LDPC_NOISE_HOST_MT19937 = 1   /* bit-exact experiment.h:97-99: frame i <- mt19937(i+1) +
+                                         libstdc++ normal_distribution, generated on the host */
+};
+
+typedef struct acg_ldpc_params {
+    int32_t algo;       /* ACG_LDPC_* */
+    int32_t max_iter;   /* BeliefPropagationDecoder(max_iter) bp.h:210 / QPADMMDecoder max_iter qp_admm.h:182 */
+    double alpha;       /* QP-ADMM (qp_admm.h:182) */
+    double mu;          /* QP-ADMM */
+    double eps_stop;    /* QP-ADMM residual threshold (qp_admm.h:161) */
+    double ms_scale;    /* min-sum normalisation factor (1.0 = plain) */
+    int32_t early_exit; /* 1 = reference semantics: stop a frame at its first zero syndrome (bp.h:195-196)
+                           / residual < eps (qp_admm.h:161).  0 = fixed work: run max_iter sweeps for every
+                           frame, output LATCHED at the first zero syndrome (identical results). */
+    int32_t precision;  /* ACG_LDPC_PREC_* */
+    int32_t device;     /* HIP device ordinal; -1 = current device */
+    int32_t lanes_per_frame; /* 0 = auto; otherwise 16/32/64 lanes of a wavefront cooperate on one frame */
+} acg_ldpc_params;
+
+void acg_ldpc_params_default(acg_ldpc_params *p);
+
+/* last error message of the calling thread ("" if none).  The reference aborts via assert();
+ * here every failure is an error code + message and nothing is silently computed on the CPU. */
+const char *acg_ldpc_last_error(void);
+
+/* 1 if a HIP device is usable from this process, 0 otherwise (never falls back to a CPU decode). */
+int acg_ldpc_device_available(void);
+
+/* ---- parity-check matrix --------------------------------------------------------------- */
+
+/* replaces: TMatrix (utils/codeword.h:18) handed to decode() on every call; analysed once here
+ * (the reference re-scans H per frame: bp.h:136-153, qp_admm.h:15-21,60-66). H: m*n bytes, !=0 -> 1. */
+int acg_ldpc_code_from_dense(const uint8_t *H, int32_t m, int32_t n, acg_ldpc_code **out);
+/* replaces read_pcm (utils/parse_data.h:6-25), same quirks */
+int acg_ldpc_code_load_txt(const char *path, acg_ldpc_code **out);
+/* replaces save_matrix (utils/parse_data.h:44-54) */
+int acg_ldpc_code_save_txt(const acg_ldpc_code *code, const char *path);
+void acg_ldpc_code_destroy(acg_ldpc_code *code);
+/* m checks, n variables, E edges (ones of H) */
+void acg_ldpc_code_dims(const acg_ldpc_code *code, int32_t *m, int32_t *n, int32_t *E);
+/* dense copy back (m*n bytes) */
+void acg_ldpc_code_dense(const acg_ldpc_code *code, uint8_t *H);
+/* QP-ADMM problem shape of ConstructADMMProblem (qp_admm.h:13-102) */
+void acg_ldpc_code_admm_shape(const acg_ldpc_code *code, int32_t *n_var, int32_t *n_con, int32_t *nnz,
+                              double *e_min, double *e_max);
+/* replaces GetOrtogonal (utils/codeword.h:97-128): G must hold (n-m)*n bytes; returns 0 ok,
+ * 1 if a row of H vanishes during elimination (the reference's {TMatrix(), false}). */
+int acg_ldpc_code_generator(const acg_ldpc_code *code, uint8_t *G);
+/* replaces IsCodeword (utils/codeword.h:90-95): 1 / 0 */
+int acg_ldpc_code_is_codeword(const acg_ldpc_code *code, const uint8_t *bits);
+
+/* ---- decoder --------------------------------------------------------------------------- */
+
+/* replaces make_shared<BeliefPropagationDecoder>(it) / make_shared<QPADMMDecoder>(a,mu,it,eps)
+ * (main.cpp:28-40).  Fails (non-zero) when no HIP device is present. */
+int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *params, acg_ldpc_decoder **out);
+void acg_ldpc_decoder_destroy(acg_ldpc_decoder *dec);
+/* replaces Decoder::name() (algo/algo.h:10): "BP" (bp.h:218), "QP-ADMM" (qp_admm.h:189), "MS" */
+const char *acg_ldpc_decoder_name(const acg_ldpc_decoder *dec);
+
+/* replaces Decoder::decode(H, y, snr) (algo/algo.h:8) for `frames` frames at once.
+ *   y      host, frames*n doubles, raw channel symbols (NOT LLRs; llr = 2y/sigma^2 is formed inside,
+ *          channel.h:12-16, bp.h:66, qp_admm.h:27)
+ *   bits   host, frames*n bytes (0/1).  BP failure -> zeros (the reference returns an empty vector, bp.h:198)
+ *   ok     host, frames bytes: the reference's bool (BP: zero syndrome reached; QP-ADMM: always 1 unless the
+ *          e_min*mu<=alpha guard fires, qp_admm.h:112-114,177)
+ *   iters  host, frames int32 or NULL: sweeps executed until exit (BP: iteration of the first zero syndrome) */
+int acg_ldpc_decode_batch(acg_ldpc_decoder *dec, const double *y, int64_t frames, double snr, uint8_t *bits,
+                          uint8_t *ok, int32_t *iters);
+
+/* Same, buffers already resident in HBM (this is what bench.py times).
+ *   y_dev        device, frames*n of float (y_is_f64=0) or double (y_is_f64=1)
+ *   bits_dev     device, frames*words uint32, words = (n+31)/32; bit v of a frame = word v>>5, bit v&31
+ *   ok_dev       device, frames bytes;  iters_dev device, frames int32 (may be NULL)
+ *   stream       hipStream_t to launch on (NULL = the decoder's own stream); asynchronous. */
+int acg_ldpc_decode_batch_dev(acg_ldpc_decoder *dec, const void *y_dev, int32_t y_is_f64, int64_t frames,
+                              double snr, uint32_t *bits_dev, uint8_t *ok_dev, int32_t *iters_dev, void *stream);
+/* block until the decoder's own stream is idle */
+int acg_ldpc_decoder_sync(acg_ldpc_decoder *dec);
+/* duration in ms of the most recent decode/mc kernel launch on this handle, measured with HIP
+ * events recorded on the launch stream (synchronises on the stop event) */
+float acg_ldpc_decoder_last_kernel_ms(acg_ldpc_decoder *dec);
+/* bytes of LDS per frame, frames resident per CU, lanes per frame chosen for this code (diagnostics) */
+void acg_ldpc_decoder_layout(const acg_ldpc_decoder *dec, int32_t *lds_bytes_per_frame, int32_t *lanes_per_frame,
+                             int32_t *frames_per_block, int32_t *grid_blocks);
+
+/* ---- Monte-Carlo loop (experiment.h) --------------------------------------------------- */
+
+typedef struct acg_ldpc_mc_cfg {
+    int64_t frames;       /* frames to simulate in THIS call */
+    int64_t first_frame;  /* global index of the first frame (shard offset; seeds derive from the global index) */
+    double snr;           /* Es/N0 dB, sigma^2 = 10^(-snr/10)/2 (channel.h:12) */
+    uint64_t seed;        /* Philox key (device noise).  Host mt19937 mode ignores it: frame i uses mt19937(i+1) */
+    int32_t noise;        /* ACG_LDPC_NOISE_* */
+    const uint8_t *codewords; /* host, n_codewords*n bytes, frame g transmits codewords[g % n_codewords];
+                                 NULL = all-zero codeword */
+    int64_t n_codewords;
+} acg_ldpc_mc_cfg;
+
+/* mirrors ExperimentResult + HammingDistanceTracker (experiment.h:25-68) */
+typedef struct acg_ldpc_mc_result {
+    int64_t correct, pseudo, total;
+    int64_t sum_hamming, sum_hamming_ok, sum_hamming_wrong;
+    int64_t sum_iters;   /* sweeps executed, for the mean-iterations figure */
+    double time_sec;     /* wall time of the call */
+    double kernel_ms;    /* device time of the decode kernel(s) */
+} acg_ldpc_mc_result;
+
+/* replaces multithread_experiment (experiment.h:125-139): transmit + decode + classify
+ * (correct / pseudo-codeword / fail) + raw-channel Hamming statistics, all on the device. */
+int acg_ldpc_mc_run(acg_ldpc_decoder *dec, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc_result *res);
+/* merge_exp_results (experiment.h:70-78): a += b (used to combine per-GPU shards on the host) */
+void acg_ldpc_mc_merge(acg_ldpc_mc_result *a, const acg_ldpc_mc_result *b);
+
+/* ---- host-side generators used by the reference's drivers (bit-exact, libstdc++) ----------- */
+
+/* replaces gen_random_codewords (utils/channel.h:28-44) with std::mt19937(seed): row i of G (k x n bytes)
+ * is XORed in when rnd() % 2 == 0.  out: count*n bytes. */
+int acg_ldpc_gen_codewords(const uint8_t *G, int32_t k, int32_t n, uint32_t seed, int64_t count, uint8_t *out);
+/* replaces transmit (utils/channel.h:18-26) as driven by exp() (experiment.h:97-99): global frame g uses
+ * std::mt19937(g+1) and std::normal_distribution<double>(0, sigma); transmits codewords[g % n_codewords]
+ * (NULL = all-zero word).  y: frames*n doubles. */
+int acg_ldpc_transmit_host(const uint8_t *codewords, int64_t n_codewords, int32_t n, int64_t first_frame,
+                           int64_t frames, double snr, double *y);
+/* llr_variance (utils/channel.h:12) */
+double acg_ldpc_llr_variance(double snr);
+
+/* device-side AWGN only (utils/channel.h:18-26 with the Philox generator): fills y_dev (frames*n floats)
+ * for global frames [first_frame, first_frame+frames). codewords as in acg_ldpc_mc_cfg (host pointer). */
+int acg_ldpc_awgn_dev(acg_ldpc_decoder *dec, const acg_ldpc_mc_cfg *cfg, float *y_dev, void *stream);
+
+/* diagnostics (used by tests/): evaluates the device phi(x) = -log(tanh(x/2)) (bp.h:34) of the BP kernels
+ * on n host values; f64 selects the double variant. */
+int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACG_LDPC_H */

@@ -1,0 +1,328 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle and the golden fixtures
+captured from the real reference.  Run with `-m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import ADMM_ITERS, BP_ITERS, MATS, SNRS, known, load, unpack
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+@pytest.fixture(scope="module")
+def A():
+    import acg_alp_ldpc_amd as A
+    assert A.device_available(), "no HIP device: the product has no CPU fallback"
+    return A
+
+
+@pytest.fixture(scope="module")
+def pcm(A, matrices):
+    return {k: A.ParityCheckMatrix(v) for k, v in matrices.items()}
+
+
+# ---------------------------------------------------------------------------------------- phi
+def test_phi_device_vs_long_double(A):
+    import ctypes as C
+    x = np.concatenate([np.logspace(-30, np.log10(45.7), 4000), np.array([0.0, 45.8, 60.0, np.inf, np.nan, 0.25, 2.0])])
+    x32 = x.astype(np.float32)
+    out = np.zeros_like(x32)
+    assert A.lib().acg_ldpc_debug_phi(x32.ctypes.data, out.ctypes.data, len(x32), 0) == 0
+    def phi_true(xl):
+        # mathematically exact phi in long double.  (The reference's own -logl(tanhl(x/2)) is quantised to
+        # multiples of 2^-64 above x ~ 38 because tanhl rounds towards 1; 2*atanh(e^-x) is used there.)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            t = np.exp(-xl)
+            return np.where(xl < 1, -np.log(np.tanh(xl / 2)), np.log1p(2 * t / (1 - t)))
+    xl = x32.astype(np.longdouble)
+    ref = phi_true(xl)
+    fin = np.isfinite(ref) & (x32 < 45.7) & (x32 > 0)
+    rel = np.abs(out[fin].astype(np.longdouble) - ref[fin]) / np.abs(ref[fin])
+    # fp32 tolerance on the soft function; x*|d phi/dx| amplification of the exp argument for large x
+    assert rel.max() < 2e-5, rel.max()
+    assert np.median(rel) < 2e-7
+    assert out[x32 == 0][0] == np.inf          # phi(0) = +inf   (bp.h:34)
+    assert (out[x32 >= 45.7477] == 0).all()   # long-double saturation point of the reference
+    assert np.isnan(out[np.isnan(x32)]).all()
+    # fp64 variant
+    o64 = np.zeros_like(x)
+    assert A.lib().acg_ldpc_debug_phi(x.ctypes.data, o64.ctypes.data, len(x), 1) == 0
+    fin = np.isfinite(ref) & (x < 45.7) & (x > 0)
+    ref64 = phi_true(x.astype(np.longdouble))
+    rel = np.abs(o64[fin] - ref64[fin]) / np.abs(ref64[fin])
+    assert rel.max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------- BP
+@pytest.mark.parametrize("name", MATS)
+@pytest.mark.parametrize("snr", SNRS)
+def test_bp_golden_hard_decisions(A, pcm, name, snr):
+    """bit-exact bits + flag vs the real reference at every fixture iteration count"""
+    g = load(name, snr)
+    H = pcm[name]
+    for it in BP_ITERS:
+        dec = A.BeliefPropagationDecoder(it)
+        bits, ok, iters = dec.decode_batch(H, g["y"], snr)
+        assert (ok == g["bp%d_ok" % it]).all(), (name, snr, it)
+        assert (bits == unpack(g["bp%d_bits" % it], H.n)).all(), (name, snr, it)
+        dec.close()
+
+
+@pytest.mark.parametrize("lpf", [16, 32, 64])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_bp_vs_oracle_2000_frames(A, oracle, matrices, pcm, lpf, prec):
+    from acg_alp_ldpc_amd import _lib
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 4242, 2000)
+    for snr in (-2.5, -1.0, 3.0):
+        y = oracle.transmit_frames(cws, snr, first_seed=100000)
+        ob, ook, oit = oracle.bp_decode(Hm, y, snr, 50, threads=8)
+        dec = A.BeliefPropagationDecoder(50, lanes_per_frame=lpf,
+                                         precision=_lib.PREC_F64 if prec == "f64" else _lib.PREC_DEFAULT)
+        bits, ok, iters = dec.decode_batch(H, y, snr)
+        dec.close()
+        assert (ok == ook).all(), (snr, int((ok != ook).sum()))
+        assert (bits == ob).all()
+        assert (iters == oit).all()
+
+
+def test_bp_fixed_work_equals_early_exit(A, oracle, matrices, pcm):
+    Hm, H = matrices["optimalH"], pcm["optimalH"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 1, 700)
+    y = oracle.transmit_frames(cws, -2.0, first_seed=1)
+    a = A.BeliefPropagationDecoder(50, early_exit=True)
+    b = A.BeliefPropagationDecoder(50, early_exit=False)
+    ra, rb = a.decode_batch(H, y, -2.0), b.decode_batch(H, y, -2.0)
+    for x, z in zip(ra, rb):
+        assert (x == z).all()
+
+
+def test_bp_edge_cases(A, oracle):
+    # ragged degrees incl. degree-1 check (phi(0)=inf message), degree-0 variable, empty check row
+    H = np.zeros((5, 9), np.uint8)
+    H[0, [0, 1, 2, 3]] = 1
+    H[1, [2, 3, 4]] = 1
+    H[2, [5]] = 1          # degree-1 check pins variable 5 to 0
+    H[3, [0, 6]] = 1       # degree-2 check
+    # row 4 empty; column 7, 8 isolated
+    rng = np.random.default_rng(3)
+    y = 1.0 + 0.9 * rng.standard_normal((300, 9))
+    ob, ook, oit = oracle.bp_decode(H, y, 0.0, 12, threads=2)
+    dec = A.BeliefPropagationDecoder(12)
+    bits, ok, iters = dec.decode_batch(H, y, 0.0)
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+    # empty batch
+    b0, o0, i0 = dec.decode_batch(H, np.zeros((0, 9)), 0.0)
+    assert b0.shape == (0, 9) and o0.shape == (0,)
+    # single-frame reference signature: failure returns an empty word (bp.h:198)
+    ybad = -np.ones(9)
+    ybad[5] = 3.0
+    word, flag = dec.decode(H, y[0], 0.0)
+    assert flag == bool(ook[0]) and (not flag or (word == ob[0]).all())
+    assert dec.name() == "BP"
+
+
+def test_bp_infinite_messages_high_snr(A, oracle, matrices, pcm):
+    # +4..+8 dB: LLR magnitudes saturate phi; flags/bits must still agree
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 9, 1500)
+    for snr in (4.0, 8.0):
+        y = oracle.transmit_frames(cws, snr, first_seed=777)
+        ob, ook, oit = oracle.bp_decode(Hm, y, snr, 50, threads=8)
+        dec = A.BeliefPropagationDecoder(50)
+        bits, ok, iters = dec.decode_batch(H, y, snr)
+        assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+
+
+# ---------------------------------------------------------------------------------------- QP-ADMM
+@pytest.mark.parametrize("name", MATS)
+@pytest.mark.parametrize("snr", SNRS)
+def test_qpadmm_golden_hard_decisions(A, pcm, name, snr):
+    g = load(name, snr)
+    H = pcm[name]
+    alpha, mu = g["admm_alpha_mu"]
+    for it in ADMM_ITERS:
+        for tag, eps in (("e0", 0.0), ("e5", 1e-5)):
+            dec = A.QPADMMDecoder(alpha, mu, it, eps)
+            bits, ok, iters = dec.decode_batch(H, g["y"], snr)
+            dec.close()
+            assert (ok == g["admm%d_%s_ok" % (it, tag)]).all()
+            assert (bits == unpack(g["admm%d_%s_bits" % (it, tag)], H.n)).all(), (name, snr, it, tag)
+
+
+@pytest.mark.parametrize("lpf", [16, 32, 64])
+def test_qpadmm_vs_oracle_iters(A, oracle, matrices, pcm, lpf):
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 11, 1000)
+    y = oracle.transmit_frames(cws, -2.0, first_seed=31337)
+    ob, ook, oit = oracle.qpadmm_decode(Hm, y, -2.0, 1.95, 0.5, 100, 1e-5, threads=8)
+    dec = A.QPADMMDecoder(1.95, 0.5, 100, 1e-5, lanes_per_frame=lpf)
+    bits, ok, iters = dec.decode_batch(H, y, -2.0)
+    assert (ok == ook).all() and (bits == ob).all()
+    assert (iters == oit).all()   # same sweep count: the residual test fires on the same sweep
+    assert dec.name() == "QP-ADMM"
+
+
+def test_qpadmm_guard_and_small_checks(A, oracle, matrices, pcm):
+    dec = A.QPADMMDecoder(2.0, 0.5, 10)          # e_min*mu = 2 <= alpha -> (zeros,false), qp_admm.h:112-114
+    y = np.ones((5, pcm["H05"].n))
+    bits, ok, iters = dec.decode_batch(pcm["H05"], y, 0.0)
+    assert not ok.any() and not bits.any()
+    # degree-1 / degree-2 checks (qp_admm.h:70-83) and an empty row
+    H = np.zeros((5, 8), np.uint8)
+    H[0, [0, 1, 2, 3, 4]] = 1
+    H[1, [2, 5]] = 1
+    H[2, [6]] = 1
+    H[3, [1, 3, 7]] = 1
+    H[4, [0, 7]] = 1
+    rng = np.random.default_rng(5)
+    y = 1.0 + 0.8 * rng.standard_normal((200, 8))
+    ob, ook, oit = oracle.qpadmm_decode(H, y, 1.0, 0.6, 1.0, 80, 1e-6, threads=2)
+    dec = A.QPADMMDecoder(0.6, 1.0, 80, 1e-6)
+    bits, ok, iters = dec.decode_batch(H, y, 1.0)
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+
+
+def test_qpadmm_fp32_fer_only(A, oracle, matrices, pcm):
+    """fp32 QP-ADMM: FER-level agreement only (the 1/(mu*e-alpha)=20x gain amplifies rounding)"""
+    from acg_alp_ldpc_amd import _lib
+    Hm, H = matrices["optimalH"], pcm["optimalH"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 3, 1000)
+    y = oracle.transmit_frames(cws, -2.0, first_seed=1)
+    ob, _, _ = oracle.qpadmm_decode(Hm, y, -2.0, 1.2, 0.55, 100, 1e-5, threads=8)
+    dec = A.QPADMMDecoder(1.2, 0.55, 100, 1e-5, precision=_lib.PREC_F32)
+    bits, ok, _ = dec.decode_batch(H, y, -2.0)
+    good_o = (ob == cws).all(axis=1).mean()
+    good_g = (bits == cws).all(axis=1).mean()
+    assert abs(good_o - good_g) < 0.03
+
+
+# ---------------------------------------------------------------------------------------- min-sum (unpinned)
+def test_minsum_against_own_restatement(A, oracle, matrices, pcm):
+    """parity unpinned (no min-sum in the reference): checked against the repo's own fp64
+    restatement; fp32 vs fp64 may differ on knife-edge frames, so agreement is asked at 99.5%."""
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 5, 2000)
+    for scale in (1.0, 0.75):
+        y = oracle.transmit_frames(cws, -1.0, first_seed=99)
+        ob, ook, oit = oracle.minsum_decode(Hm, y, -1.0, 50, scale, threads=8)
+        dec = A.MinSumDecoder(50, scale)
+        bits, ok, iters = dec.decode_batch(H, y, -1.0)
+        agree = ((ok == ook) & (bits == ob).all(axis=1)).mean()
+        assert agree >= 0.995, agree
+        from acg_alp_ldpc_amd import _lib
+        dec64 = A.MinSumDecoder(50, scale, precision=_lib.PREC_F64)
+        bits, ok, iters = dec64.decode_batch(H, y, -1.0)
+        assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+
+
+# ---------------------------------------------------------------------------------------- Monte-Carlo
+@pytest.mark.parametrize("idx", [0, 2, 3, 6, 7, 10, 12])
+def test_mc_host_noise_known_answers(A, matrices, pcm, idx):
+    """experiment.h loop with the reference's exact frames (mt19937(i+1)): counts identical to the
+    single-threaded reference run recorded in tests/golden/known_answers.json"""
+    e = known()["experiments"][idx]
+    H = pcm[e["matrix"]]
+    if e["codewords"].startswith("G05"):
+        from oracle.pyoracle import Oracle
+        G = Oracle().read_pcm(os.path.join(DATA, "G05.txt"))
+    else:
+        G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 1000, 239239239)
+    if e["kind"] == "bp":
+        dec = A.BeliefPropagationDecoder(e["max_iter"])
+    else:
+        dec = A.QPADMMDecoder(e["alpha"], e["mu"], e["max_iter"], 1e-5)
+    r = A.run_experiment(dec, cws, H, e["snr"], noise="host")
+    for k in ("correct", "pseudo", "total", "sum_hamming", "sum_hamming_ok", "sum_hamming_wrong"):
+        assert getattr(r, k) == e[k], (k, r, e)
+
+
+def test_mc_device_noise_statistics(A, matrices, pcm):
+    """Philox AWGN is validated statistically only: raw BER = Q(1/sigma), FER inside the
+    99% binomial interval around the reference's 1000-frame estimate, shard-count invariance."""
+    from math import erfc, sqrt
+    H = pcm["H05"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 4096, 239239239)
+    dec = A.BeliefPropagationDecoder(50)
+    F = 200000
+    snr = -2.0
+    r = A.run_experiment(dec, cws, H, snr, frames=F, noise="device", seed=12345)
+    assert r.total == F
+    sigma = sqrt(A.llr_variance(snr))
+    ber = 0.5 * erfc(1 / sigma / sqrt(2))
+    assert abs(r.mean_hamming() / H.n - ber) < 4 * sqrt(ber * (1 - ber) / (F * H.n))
+    p_ref = 1 - 915 / 1000.0   # known_answers: H05 BP-50 @ -2 dB
+    half = 2.576 * sqrt(p_ref * (1 - p_ref) / 1000) + 2.576 * sqrt(p_ref * (1 - p_ref) / F)
+    assert abs(r.FER() - p_ref) < half, (r.FER(), p_ref)
+    # same global frames in 1 shard or 3 shards
+    parts = [A.run_experiment(dec, cws, H, snr, frames=c, first_frame=lo, noise="device", seed=12345)
+             for lo, c in (A.shard_range(F, k, 3) for k in range(3))]
+    tot = parts[0]
+    for p in parts[1:]:
+        A.merge_exp_results(tot, p)
+    assert (tot.as_vector() == r.as_vector()).all()
+    # QP-ADMM through the same loop
+    adm = A.QPADMMDecoder(1.95, 0.5, 100, 1e-5)
+    ra = A.run_experiment(adm, cws, H, snr, frames=20000, noise="device", seed=5)
+    p_ref = 1 - 660 / 1000.0
+    assert abs(ra.FER() - p_ref) < 2.576 * sqrt(p_ref * (1 - p_ref) / 1000) + 0.01, ra.FER()
+
+
+def test_awgn_dev_matches_mc_frames(A, pcm):
+    """the standalone AWGN generator and the in-kernel one produce the same frames (same Philox keys):
+    decoding the generated y through decode_batch_dev gives the same counters as the MC kernel."""
+    import ctypes as C
+    import torch
+    from acg_alp_ldpc_amd._lib import McCfg, check, lib
+    H = pcm["H05"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 512, 1)
+    dec = A.BeliefPropagationDecoder(50)
+    F, snr = 8192, -1.5
+    h, _ = dec.handle(H)
+    cfg = McCfg()
+    cfg.frames, cfg.first_frame, cfg.snr, cfg.seed, cfg.noise = F, 1000, snr, 99, 0
+    cfg.codewords, cfg.n_codewords = cws.ctypes.data, cws.shape[0]
+    y = torch.empty((F, H.n), dtype=torch.float32, device="cuda")
+    check(lib().acg_ldpc_awgn_dev(h, C.byref(cfg), y.data_ptr(), None))
+    dec.sync(H)
+    nw = (H.n + 31) // 32
+    bits = torch.zeros((F, nw), dtype=torch.int32, device="cuda")
+    ok = torch.zeros(F, dtype=torch.uint8, device="cuda")
+    it = torch.zeros(F, dtype=torch.int32, device="cuda")
+    dec.decode_batch_dev(H, y.data_ptr(), False, F, snr, bits.data_ptr(), ok.data_ptr(), it.data_ptr())
+    dec.sync(H)
+    r = A.run_experiment(dec, cws, H, snr, frames=F, first_frame=1000, noise="device", seed=99)
+    okh = ok.cpu().numpy()
+    assert int(it.sum().item()) == r.sum_iters
+    assert int(okh.sum()) == r.correct + r.pseudo
+    ysum = float(y.double().mean().item())
+    assert abs(ysum - float((1 - 2 * cws.astype(np.float64)).mean())) < 0.02
+
+
+# ---------------------------------------------------------------------------------------- full-size properties
+def test_full_size_round_trip_properties(A, pcm):
+    """BASELINE config-2 size (1M frames) through size-independent properties: encode -> AWGN -> decode
+    returns the sent word whenever ok, every returned word has zero syndrome, totals add up."""
+    H = pcm["H05"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 8192, 2024)
+    dec = A.BeliefPropagationDecoder(50)
+    F = 1 << 20
+    r = A.run_experiment(dec, cws, H, 2.0, frames=F, noise="device", seed=1)
+    assert r.total == F and r.correct + r.pseudo <= F
+    assert r.sum_hamming == r.sum_hamming_ok + r.sum_hamming_wrong
+    assert r.FER() < 1e-3               # +2 dB: reference FER is 0/1000
+    assert r.pseudo <= 5
+    r0 = A.run_experiment(dec, None, H, 2.0, frames=F, noise="device", seed=1)  # all-zero codeword
+    assert r0.total == F and abs(r0.FER() - r.FER()) < 1e-3  # decoder symmetry
