@@ -22,9 +22,9 @@ namespace acg {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
-hipError_t bp_launch(int algo, int f64, int maxd, int L, const BpTables &t, const DecodeArgs &a, int grid, int block,
-                     size_t lds, hipStream_t s);
-const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc);
+hipError_t bp_launch(const void *kernel, const BpTables &t, const DecodeArgs &a, int grid, int block, size_t lds,
+                     hipStream_t s);
+const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc, bool idxlds);
 hipError_t phi_debug_launch(const void *x, void *out, int n, int f64, hipStream_t s);
 hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t first_frame, uint64_t seed,
                        const uint32_t *cw_packed, int64_t n_cw, float sigma, hipStream_t s);
@@ -75,7 +75,9 @@ struct acg_ldpc_decoder {
     BpTables tab{};
     std::vector<void *> dev_allocs;
     int maxd = 0, f64 = 0, L = 64;
-    int block = 256, grid_cap = 0, frames_per_block = 0;
+    int block = 256, frames_per_block = 0;
+    int grid_cap[2] = {0, 0};          // [mc] resident blocks: occupancy x CUs
+    const void *kernel[2] = {nullptr, nullptr};
     size_t lds_block = 0;
     // ADMM
     AdmmDevice *admm = nullptr;
@@ -217,21 +219,36 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     BpTables &t = d->tab;
     int32_t *p32 = nullptr;
     uint16_t *p16 = nullptr;
+    std::vector<int32_t> c_pass(2 * (size_t) lay.n_cpass), v_pass(2 * (size_t) lay.n_vpass);
+    for (int p = 0; p < lay.n_cpass; p++) {
+        c_pass[2 * p] = lay.c_maxdeg[p];
+        c_pass[2 * p + 1] = lay.c_off[p];
+    }
+    for (int p = 0; p < lay.n_vpass; p++) {
+        v_pass[2 * p] = lay.v_maxdeg[p];
+        v_pass[2 * p + 1] = lay.v_idx_off[p];
+    }
+    std::vector<int32_t> c_cnt(34, 0), v_cnt(34, 0);
+    for (size_t i = 0; i < lay.c_cnt_ge.size() && i < 34; i++) c_cnt[i] = lay.c_cnt_ge[i];
+    for (size_t i = 0; i < lay.v_cnt_ge.size() && i < 34; i++) v_cnt[i] = lay.v_cnt_ge[i];
 #define UP32(vec, field)                                       \
     if (upload<int32_t>(vec, &p32)) return 10;                 \
     d->dev_allocs.push_back(p32);                              \
     t.field = p32;
-    UP32(lay.c_maxdeg, c_maxdeg)
-    UP32(lay.c_off, c_off)
-    UP32(lay.c_cnt_ge, c_cnt_ge)
-    UP32(lay.v_maxdeg, v_maxdeg)
-    UP32(lay.v_idx_off, v_idx_off)
-    UP32(lay.v_cnt_ge, v_cnt_ge)
+    UP32(c_pass, c_pass)
+    UP32(c_cnt, c_cnt_ge)
+    UP32(v_pass, v_pass)
+    UP32(v_cnt, v_cnt_ge)
     UP32(lay.v_var, v_var)
 #undef UP32
     if (upload<uint16_t>(lay.v_apos, &p16)) return 10;
     d->dev_allocs.push_back(p16);
     t.v_apos = p16;
+    t.v_apos_len = lay.v_apos_len;
+    // the variable-side index table is read by every wave in every iteration: keep a block-shared
+    // copy in LDS unless it is large (then it is read through L1/L2)
+    const bool idxlds = (size_t) lay.v_apos_len * 2 <= 16 * 1024;
+    t.idx_lds_bytes = idxlds ? (int) (((size_t) lay.v_apos_len * 2 + 15) & ~(size_t) 15) : 0;
     t.n_cpass = lay.n_cpass;
     t.n_vpass = lay.n_vpass;
     t.a_words = lay.a_words;
@@ -243,20 +260,19 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     t.lds_bytes_per_frame = (int) per_frame;
 
     const int fpw = 64 / L;
-    // waves per block: as many as fit in 64 KiB of LDS (so several blocks share a CU), at most 4
+    // waves per block: as many as fit in half the LDS (so at least two blocks share a CU), at most 4
     int waves = 4;
-    while (waves > 1 && per_frame * fpw * waves > 160 * 1024 / 2) waves >>= 1;
-    if (per_frame * fpw * waves > 160 * 1024) {
+    while (waves > 1 && per_frame * fpw * waves + t.idx_lds_bytes > 160 * 1024 / 2) waves >>= 1;
+    if (per_frame * fpw * waves + t.idx_lds_bytes > 160 * 1024) {
         set_error("frame state does not fit in LDS (160 KiB per CU)");
         return 3;
     }
     d->block = waves * 64;
     d->frames_per_block = waves * fpw;
-    d->lds_block = per_frame * fpw * waves;
+    d->lds_block = per_frame * fpw * waves + t.idx_lds_bytes;
     const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
-    int per_cu = 0;
     for (int mc = 0; mc < 2; mc++) {
-        const void *kp = bp_kernel_ptr(algo, d->f64, d->maxd, L, mc != 0);
+        const void *kp = bp_kernel_ptr(algo, d->f64, d->maxd, L, mc != 0, idxlds);
         if (!kp) {
             set_error("no kernel instance for this configuration");
             return 3;
@@ -266,9 +282,9 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
         int occ = 0;
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, d->block, d->lds_block));
         if (occ < 1) occ = 1;
-        per_cu = (mc == 0) ? occ : std::min(per_cu, occ);
+        d->kernel[mc] = kp;
+        d->grid_cap[mc] = occ * d->cu_count;
     }
-    d->grid_cap = per_cu * d->cu_count;
     return 0;
 }
 
@@ -358,7 +374,7 @@ void acg_ldpc_decoder_layout(const acg_ldpc_decoder *d, int32_t *lds_bytes_per_f
     if (lds_bytes_per_frame) *lds_bytes_per_frame = d->tab.lds_bytes_per_frame;
     if (lanes_per_frame) *lanes_per_frame = d->L;
     if (frames_per_block) *frames_per_block = d->frames_per_block;
-    if (grid_blocks) *grid_blocks = d->grid_cap;
+    if (grid_blocks) *grid_blocks = d->grid_cap[0];
 }
 
 static void fill_channel(DecodeArgs &a, double snr) {
@@ -384,9 +400,9 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         }
     } else {
         int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
-        int grid = (int) std::min<int64_t>(blocks, d->grid_cap);
-        const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
-        HIP_OK(bp_launch(algo, d->f64, d->maxd, d->L, d->tab, a, grid, d->block, d->lds_block, s));
+        const int mc = a.mc ? 1 : 0;
+        int grid = (int) std::min<int64_t>(blocks, d->grid_cap[mc]);
+        HIP_OK(bp_launch(d->kernel[mc], d->tab, a, grid, d->block, d->lds_block, s));
     }
     HIP_OK(hipEventRecord(d->ev1, s));
     d->ev_valid = true;

@@ -126,8 +126,133 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, fl
 }
 
 // ------------------------------------------------------------------------------------------
+// Wave-uniform tables are read through the constant address space so the compiler issues scalar
+// (SMEM) loads into SGPRs instead of per-lane vector loads followed by v_readfirstlane.
+typedef const int32_t __attribute__((address_space(4))) *sconst_i32;
+__device__ __forceinline__ int sload(const int32_t *p, int i) { return ((sconst_i32) (p))[i]; }
+
+// ------------------------------------------------------------------------------------------
+// One pass = the L nodes dealt to the L lanes of a frame group.  D (the largest degree in the
+// pass) is a compile-time constant: the D LDS reads are issued back to back, then everything is
+// straight-line register code, then the D LDS writes.  Dispatch on D is a wave-uniform switch.
+template <typename T, int D, int L, int ALGO>
+struct BpPass {
+    using B = FpBits<T>;
+    using U = typename B::U;
+    static constexpr U SIGN = B::SIGN;
+    static constexpr U ONE = (U) 1;
+
+    // syndrome contribution of the checks in this pass (LSB of the XOR of the v->c words)
+    static __device__ __forceinline__ U syn(const T *__restrict__ Ap) {
+        T x[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = Ap[j * L];
+        U S = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) S ^= B::to(x[j]);
+        return S;
+    }
+
+    // check -> variable (bp.h:171-181 / CNode::message bp.h:49-57), in place.  cnt[j] = number of
+    // checks of degree >= j: slot < cnt[j+1] <=> edge j of this lane's check exists.
+    static __device__ __forceinline__ void check(T *__restrict__ Ap, int slot, const int *cnt, bool write, T ms_scale) {
+        T x[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = Ap[j * L];
+        U S = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) S ^= B::to(x[j]);
+        T out[D];
+        if (ALGO == 0) {
+            // exclude-self sums of the phi magnitudes: prefix + suffix (bp.h:50-55)
+            T mag[D], pre[D];
+            T s = 0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                mag[j] = B::from(B::to(x[j]) & ~SIGN);
+                pre[j] = s;
+                s += mag[j];
+            }
+            T suf = 0;
+#pragma unroll
+            for (int j = D - 1; j >= 0; --j) {
+                out[j] = phi_f(pre[j] + suf);
+                suf += mag[j];
+            }
+        } else {
+            // min-sum: two smallest magnitudes (padding slots are +0 and must not take part)
+            T m1 = (T) INFINITY, m2 = (T) INFINITY;
+            int am = -1;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const T a = B::from(B::to(x[j]) & ~SIGN);
+                const bool real = slot < cnt[j + 1];
+                const bool lt1 = real && (a < m1);
+                const bool lt2 = real && (a < m2);
+                m2 = lt1 ? m1 : (lt2 ? a : m2);
+                am = lt1 ? j : am;
+                m1 = lt1 ? a : m1;
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j) out[j] = ms_scale * ((j == am) ? m2 : m1);
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const U ob = (B::to(out[j]) & ~SIGN) | ((S ^ B::to(x[j])) & SIGN);  // sign product, bp.h:54
+            if (write && slot < cnt[j + 1]) Ap[j * L] = B::from(ob);
+        }
+    }
+
+    // variable -> check (bp.h:160-169 / VNode::message bp.h:77-83) + posterior hard decision
+    // (bp.h:85-90,193), whose bit rides in the LSB of every outgoing magnitude.
+    template <typename IdxPtr>
+    static __device__ __forceinline__ void var(T *__restrict__ A, IdxPtr ip, T llr, int slot, const int *cnt, bool write) {
+        int pos[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) pos[k] = ip[k * L];
+        T c[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) c[k] = A[pos[k]];
+        T pre[D];
+        T s = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            pre[k] = s;
+            s += c[k];
+        }
+        const T total = llr + s;                            // estimate(), bp.h:85-90
+        const U hard = (total <= (T) 0) ? ONE : (U) 0;      // bp.h:193 (NaN -> 0)
+        T suf = 0;
+        U ob[D];
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) {
+            const T xk = llr + (pre[k] + suf);              // bp.h:78-82
+            suf += c[k];
+            const T ax = B::from(B::to(xk) & ~SIGN);
+            const T mg = (ALGO == 0) ? phi_f(ax) : ax;
+            ob[k] = (B::to(mg) & ~SIGN & ~ONE) | hard | ((xk <= (T) 0) ? SIGN : (U) 0);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (write && slot < cnt[k + 1]) A[pos[k]] = B::from(ob[k]);
+    }
+};
+
+#define ACG_PASS_SWITCH(md, CALL)                                                                              \
+    switch (md) {                                                                                              \
+        case 1: CALL(1); break;                                                                                \
+        case 2: CALL(2); break;                                                                                \
+        case 3: CALL(3); break;                                                                                \
+        case 4: CALL(4); break;                                                                                \
+        case 5: CALL(5); break;                                                                                \
+        case 6: CALL(6); break;                                                                                \
+        case 7: CALL(7); break;                                                                                \
+        case 8: CALL(8); break;                                                                                \
+        default: break;                                                                                        \
+    }
+
 // One frame-group's view of the kernel state.
-template <typename T, int MAXD, int L, int ALGO>
+template <typename T, int MAXD, int L, int ALGO, bool IDXLDS>
 struct BpCore {
     using B = FpBits<T>;
     using U = typename B::U;
@@ -135,136 +260,141 @@ struct BpCore {
     static constexpr U ONE = (U) 1;
 
     const BpTables &t;
-    T *__restrict__ A;    // messages, in place (LDS)
-    T *__restrict__ LLR;  // channel LLR per variable slot (LDS)
+    T *__restrict__ A;          // messages, in place (LDS)
+    T *__restrict__ LLR;        // channel LLR per variable slot (LDS)
     uint32_t *__restrict__ OB;  // packed hard decisions staging (LDS)
-    const int l;          // lane within the frame group
-    const float ms_scale;
+    const uint16_t *IDX;        // variable-side index table: block-shared LDS copy or global
+    const int l;                // lane within the frame group
+    const T ms_scale;
+    int ccnt[MAXD + 2], vcnt[MAXD + 2];  // wave-uniform (SGPR) degree histograms
 
-    __device__ BpCore(const BpTables &t_, T *A_, T *LLR_, uint32_t *OB_, int l_, float s_)
-        : t(t_), A(A_), LLR(LLR_), OB(OB_), l(l_), ms_scale(s_) {}
+    __device__ BpCore(const BpTables &t_, T *A_, T *LLR_, uint32_t *OB_, const uint16_t *IDX_, int l_, float s_)
+        : t(t_), A(A_), LLR(LLR_), OB(OB_), IDX(IDX_), l(l_), ms_scale((T) s_) {
+#pragma unroll
+        for (int j = 0; j < MAXD + 2; ++j) {
+            ccnt[j] = sload(t.c_cnt_ge, j);
+            vcnt[j] = sload(t.v_cnt_ge, j);
+        }
+    }
 
     // XOR of the hard-decision bits of each check's variables -> true if any check of this lane fails
     __device__ __forceinline__ bool syndrome_bad() const {
         U acc = 0;
         for (int p = 0; p < t.n_cpass; ++p) {
-            const int md = t.c_maxdeg[p];
-            const T *Ap = A + t.c_off[p] + l;
-            U S = 0;
-#pragma unroll
-            for (int j = 0; j < MAXD; ++j)
-                if (j < md) S ^= B::to(Ap[j * L]);
-            acc |= S;
+            const int md = sload(t.c_pass, 2 * p);
+            const T *Ap = A + sload(t.c_pass, 2 * p + 1) + l;
+            if (MAXD <= 8 || md <= 8) {
+#define ACG_CALL(D) acc |= BpPass<T, D, L, ALGO>::syn(Ap)
+                ACG_PASS_SWITCH(md, ACG_CALL)
+#undef ACG_CALL
+            } else {
+                U S = 0;
+                for (int j = 0; j < md; ++j) S ^= B::to(Ap[j * L]);
+                acc |= S;
+            }
         }
         return (acc & ONE) != 0;
     }
 
-    // check -> variable half-iteration (bp.h:171-181 / CNode::message bp.h:49-57), in place
     __device__ __forceinline__ void check_phase(bool write) {
         for (int p = 0; p < t.n_cpass; ++p) {
-            const int md = t.c_maxdeg[p];
-            T *Ap = A + t.c_off[p] + l;
+            const int md = sload(t.c_pass, 2 * p);
+            T *Ap = A + sload(t.c_pass, 2 * p + 1) + l;
             const int slot = p * L + l;
-            T x[MAXD];
-            U S = 0;
-#pragma unroll
-            for (int j = 0; j < MAXD; ++j)
-                if (j < md) {
-                    x[j] = Ap[j * L];
-                    S ^= B::to(x[j]);
-                }
-            if (ALGO == 0) {
-                // exclude-self sums of the phi-magnitudes: prefix + suffix
-                T pre[MAXD];
-                T s = 0;
-#pragma unroll
-                for (int j = 0; j < MAXD; ++j)
-                    if (j < md) {
-                        pre[j] = s;
-                        s += B::from(B::to(x[j]) & ~SIGN);
-                    }
-                T suf = 0;
-#pragma unroll
-                for (int j = MAXD - 1; j >= 0; --j)
-                    if (j < md) {
-                        const T ex = pre[j] + suf;
-                        suf += B::from(B::to(x[j]) & ~SIGN);
-                        const T ph = phi_f(ex);
-                        const U ob = (B::to(ph) & ~SIGN) | ((S ^ B::to(x[j])) & SIGN);
-                        if (write && slot < t.c_cnt_ge[j + 1]) Ap[j * L] = B::from(ob);
-                    }
+            if (MAXD <= 8 || md <= 8) {
+#define ACG_CALL(D) BpPass<T, D, L, ALGO>::check(Ap, slot, ccnt, write, ms_scale)
+                ACG_PASS_SWITCH(md, ACG_CALL)
+#undef ACG_CALL
             } else {
-                // min-sum: two smallest magnitudes (padding slots are +0 and must not take part)
-                T m1 = (T) INFINITY, m2 = (T) INFINITY;
-                int am = -1;
-#pragma unroll
-                for (int j = 0; j < MAXD; ++j)
-                    if (j < md) {
-                        const T a = B::from(B::to(x[j]) & ~SIGN);
-                        const bool real = slot < t.c_cnt_ge[j + 1];
-                        const bool lt1 = real && (a < m1);
-                        const bool lt2 = real && (a < m2);
-                        m2 = lt1 ? m1 : (lt2 ? a : m2);
-                        am = lt1 ? j : am;
-                        m1 = lt1 ? a : m1;
-                    }
-#pragma unroll
-                for (int j = 0; j < MAXD; ++j)
-                    if (j < md) {
-                        const T mg = (T) ms_scale * ((j == am) ? m2 : m1);
-                        const U ob = (B::to(mg) & ~SIGN) | ((S ^ B::to(x[j])) & SIGN);
-                        if (write && slot < t.c_cnt_ge[j + 1]) Ap[j * L] = B::from(ob);
-                    }
+                check_generic(Ap, slot, md, write);
             }
         }
     }
 
-    // variable -> check half-iteration (bp.h:160-169 / VNode::message bp.h:77-83) plus the posterior
-    // hard decision (bp.h:85-90,193), whose bit is stored in the LSB of every outgoing magnitude.
     __device__ __forceinline__ void var_phase(bool write) {
         for (int p = 0; p < t.n_vpass; ++p) {
-            const int md = t.v_maxdeg[p];
-            const uint16_t *ip = t.v_apos + t.v_idx_off[p] + l;
+            const int md = sload(t.v_pass, 2 * p);
+            const int ioff = sload(t.v_pass, 2 * p + 1);
             const int slot = p * L + l;
             const T llr = LLR[slot];
-            int pos[MAXD];
-            T c[MAXD];
-#pragma unroll
-            for (int k = 0; k < MAXD; ++k)
-                if (k < md) {
-                    pos[k] = ip[k * L];
-                    c[k] = A[pos[k]];
-                }
-            T pre[MAXD];
-            T s = 0;
-#pragma unroll
-            for (int k = 0; k < MAXD; ++k)
-                if (k < md) {
-                    pre[k] = s;
-                    s += c[k];
-                }
-            const T total = llr + s;             // estimate(), bp.h:85-90
-            const U hard = (total <= (T) 0) ? ONE : (U) 0;  // bp.h:193 (NaN -> 0)
+            const uint16_t *ip = IDX + ioff + l;
+            if (MAXD <= 8 || md <= 8) {
+#define ACG_CALL(D) BpPass<T, D, L, ALGO>::var(A, ip, llr, slot, vcnt, write)
+                ACG_PASS_SWITCH(md, ACG_CALL)
+#undef ACG_CALL
+            } else {
+                var_generic(ip, llr, slot, md, write);
+            }
+        }
+    }
+
+    // ---- degree > 8: rolled loops (rare: high-rate codes); same arithmetic -------------------
+    __device__ __noinline__ void check_generic(T *__restrict__ Ap, int slot, int md, bool write) {
+        T x[MAXD], pre[MAXD];
+        U S = 0;
+        T s = 0;
+        for (int j = 0; j < md; ++j) {
+            x[j] = Ap[j * L];
+            S ^= B::to(x[j]);
+            pre[j] = s;
+            s += B::from(B::to(x[j]) & ~SIGN);
+        }
+        if (ALGO == 0) {
             T suf = 0;
-#pragma unroll
-            for (int k = MAXD - 1; k >= 0; --k)
-                if (k < md) {
-                    const T ex = pre[k] + suf;
-                    suf += c[k];
-                    const T xk = llr + ex;        // bp.h:82
-                    const T ax = B::from(B::to(xk) & ~SIGN);
-                    const T mg = (ALGO == 0) ? phi_f(ax) : ax;
-                    const U ob = (B::to(mg) & ~SIGN & ~ONE) | hard | ((xk <= (T) 0) ? SIGN : (U) 0);
-                    if (write && slot < t.v_cnt_ge[k + 1]) A[pos[k]] = B::from(ob);
-                }
+            for (int j = md - 1; j >= 0; --j) {
+                const T ph = phi_f(pre[j] + suf);
+                suf += B::from(B::to(x[j]) & ~SIGN);
+                const U ob = (B::to(ph) & ~SIGN) | ((S ^ B::to(x[j])) & SIGN);
+                if (write && slot < ccnt[j + 1]) Ap[j * L] = B::from(ob);
+            }
+        } else {
+            T m1 = (T) INFINITY, m2 = (T) INFINITY;
+            int am = -1;
+            for (int j = 0; j < md; ++j) {
+                const T a = B::from(B::to(x[j]) & ~SIGN);
+                const bool real = slot < ccnt[j + 1];
+                const bool lt1 = real && (a < m1);
+                const bool lt2 = real && (a < m2);
+                m2 = lt1 ? m1 : (lt2 ? a : m2);
+                am = lt1 ? j : am;
+                m1 = lt1 ? a : m1;
+            }
+            for (int j = 0; j < md; ++j) {
+                const T mg = ms_scale * ((j == am) ? m2 : m1);
+                const U ob = (B::to(mg) & ~SIGN) | ((S ^ B::to(x[j])) & SIGN);
+                if (write && slot < ccnt[j + 1]) Ap[j * L] = B::from(ob);
+            }
+        }
+    }
+
+    __device__ __noinline__ void var_generic(const uint16_t *ip, T llr, int slot, int md, bool write) {
+        int pos[MAXD];
+        T c[MAXD], pre[MAXD];
+        T s = 0;
+        for (int k = 0; k < md; ++k) {
+            pos[k] = ip[k * L];
+            c[k] = A[pos[k]];
+            pre[k] = s;
+            s += c[k];
+        }
+        const T total = llr + s;
+        const U hard = (total <= (T) 0) ? ONE : (U) 0;
+        T suf = 0;
+        for (int k = md - 1; k >= 0; --k) {
+            const T xk = llr + (pre[k] + suf);
+            suf += c[k];
+            const T ax = B::from(B::to(xk) & ~SIGN);
+            const T mg = (ALGO == 0) ? phi_f(ax) : ax;
+            const U ob = (B::to(mg) & ~SIGN & ~ONE) | hard | ((xk <= (T) 0) ? SIGN : (U) 0);
+            if (write && slot < vcnt[k + 1]) A[pos[k]] = B::from(ob);
         }
     }
 
     // hard decision of the variable in (pass p, this lane) as stored by the last var_phase
     __device__ __forceinline__ uint32_t hard_bit(int p) const {
         const int slot = p * L + l;
-        if (slot < t.v_cnt_ge[1]) {
-            const int pos0 = t.v_apos[t.v_idx_off[p] + l];
+        if (slot < vcnt[1]) {
+            const int pos0 = IDX[sload(t.v_pass, 2 * p + 1) + l];
             return (uint32_t) (B::to(A[pos0]) & ONE);
         }
         return (LLR[slot] <= (T) 0) ? 1u : 0u;  // isolated variable: estimate() == channel LLR
@@ -299,10 +429,10 @@ __device__ __forceinline__ int group_sum(int v, int l) {
 }
 
 // ------------------------------------------------------------------------------------------
-template <typename T, int MAXD, int L, int ALGO, bool MC>
+template <typename T, int MAXD, int L, int ALGO, bool MC, bool IDXLDS>
 __global__ void __launch_bounds__(256) bp_fused_kernel(const BpTables t, const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using Core = BpCore<T, MAXD, L, ALGO>;
+    using Core = BpCore<T, MAXD, L, ALGO, IDXLDS>;
     constexpr int FPW = 64 / L;  // frames in flight per wavefront
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -310,11 +440,19 @@ __global__ void __launch_bounds__(256) bp_fused_kernel(const BpTables t, const D
     const int g = lane / L;
     const int waves_per_block = blockDim.x >> 6;
     const int grp_in_block = wave * FPW + g;
-    unsigned char *base = smem + (size_t) grp_in_block * t.lds_bytes_per_frame;
+    // block-shared copy of the variable-side index table (read every iteration by every wave)
+    const uint16_t *IDX = t.v_apos;
+    if (IDXLDS) {
+        uint16_t *idx_lds = reinterpret_cast<uint16_t *>(smem);
+        for (int i = threadIdx.x; i < t.v_apos_len; i += blockDim.x) idx_lds[i] = t.v_apos[i];
+        __syncthreads();
+        IDX = idx_lds;
+    }
+    unsigned char *base = smem + t.idx_lds_bytes + (size_t) grp_in_block * t.lds_bytes_per_frame;
     T *A = reinterpret_cast<T *>(base);
     T *LLR = A + t.a_words;
     uint32_t *OB = reinterpret_cast<uint32_t *>(LLR + t.llr_words);
-    Core core(t, A, LLR, OB, l, a.ms_scale);
+    Core core(t, A, LLR, OB, IDX, l, a.ms_scale);
 
     const int64_t n_groups = (int64_t) gridDim.x * waves_per_block * FPW;
     int64_t frame = ((int64_t) blockIdx.x * waves_per_block + wave) * FPW + g;
@@ -468,18 +606,11 @@ __global__ void __launch_bounds__(256) bp_fused_kernel(const BpTables t, const D
 // ------------------------------------------------------------------------------------------
 // host-visible launcher table
 template <typename T, int MAXD, int L, int ALGO>
-static hipError_t launch_one(const BpTables &t, const DecodeArgs &a, int grid, int block, size_t lds, hipStream_t s) {
-    if (a.mc)
-        hipLaunchKernelGGL((bp_fused_kernel<T, MAXD, L, ALGO, true>), dim3(grid), dim3(block), lds, s, t, a);
-    else
-        hipLaunchKernelGGL((bp_fused_kernel<T, MAXD, L, ALGO, false>), dim3(grid), dim3(block), lds, s, t, a);
-    return hipGetLastError();
-}
-
-template <typename T, int MAXD, int L, int ALGO>
-static const void *kernel_ptr(bool mc) {
-    return mc ? (const void *) bp_fused_kernel<T, MAXD, L, ALGO, true>
-              : (const void *) bp_fused_kernel<T, MAXD, L, ALGO, false>;
+static const void *kernel_ptr(bool mc, bool idxlds) {
+    if (mc) return idxlds ? (const void *) bp_fused_kernel<T, MAXD, L, ALGO, true, true>
+                          : (const void *) bp_fused_kernel<T, MAXD, L, ALGO, true, false>;
+    return idxlds ? (const void *) bp_fused_kernel<T, MAXD, L, ALGO, false, true>
+                  : (const void *) bp_fused_kernel<T, MAXD, L, ALGO, false, false>;
 }
 
 #define ACG_DISPATCH_L(T, MAXD, ALGO, CALL)           \
@@ -490,16 +621,8 @@ static const void *kernel_ptr(bool mc) {
         default: return nullptr;                      \
     }
 
-using LaunchFn = hipError_t (*)(const BpTables &, const DecodeArgs &, int, int, size_t, hipStream_t);
-using PtrFn = const void *(*) (bool);
+using PtrFn = const void *(*) (bool, bool);
 
-template <typename T, int ALGO>
-static LaunchFn pick_launch(int maxd, int L) {
-    if (maxd <= 8) { ACG_DISPATCH_L(T, 8, ALGO, launch_one) }
-    if (maxd <= 16) { ACG_DISPATCH_L(T, 16, ALGO, launch_one) }
-    if (maxd <= 32) { ACG_DISPATCH_L(T, 32, ALGO, launch_one) }
-    return nullptr;
-}
 template <typename T, int ALGO>
 static PtrFn pick_ptr(int maxd, int L) {
     if (maxd <= 8) { ACG_DISPATCH_L(T, 8, ALGO, kernel_ptr) }
@@ -509,20 +632,19 @@ static PtrFn pick_ptr(int maxd, int L) {
 }
 
 // algo: 0 sum-product, 1 min-sum; f64: 0/1
-hipError_t bp_launch(int algo, int f64, int maxd, int L, const BpTables &t, const DecodeArgs &a, int grid, int block,
-                     size_t lds, hipStream_t s) {
-    LaunchFn fn = nullptr;
-    if (algo == 0) fn = f64 ? pick_launch<double, 0>(maxd, L) : pick_launch<float, 0>(maxd, L);
-    else fn = f64 ? pick_launch<double, 1>(maxd, L) : pick_launch<float, 1>(maxd, L);
-    if (!fn) return hipErrorInvalidValue;
-    return fn(t, a, grid, block, lds, s);
-}
-
-const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc) {
+const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc, bool idxlds) {
     PtrFn fn = nullptr;
     if (algo == 0) fn = f64 ? pick_ptr<double, 0>(maxd, L) : pick_ptr<float, 0>(maxd, L);
     else fn = f64 ? pick_ptr<double, 1>(maxd, L) : pick_ptr<float, 1>(maxd, L);
-    return fn ? fn(mc) : nullptr;
+    return fn ? fn(mc, idxlds) : nullptr;
+}
+
+hipError_t bp_launch(const void *kernel, const BpTables &t, const DecodeArgs &a, int grid, int block, size_t lds,
+                     hipStream_t s) {
+    BpTables tt = t;
+    DecodeArgs aa = a;
+    void *args[2] = {&tt, &aa};
+    return hipLaunchKernel(kernel, dim3(grid), dim3(block), args, lds, s);
 }
 
 // ------------------------------------------------------------------------------------------

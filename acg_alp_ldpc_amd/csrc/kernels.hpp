@@ -7,14 +7,14 @@ namespace acg {
 
 // Device copies of BpLayout (see ldpc_internal.hpp for the meaning of each table).
 struct BpTables {
-    const int32_t *c_maxdeg;
-    const int32_t *c_off;
-    const int32_t *c_cnt_ge;
-    const int32_t *v_maxdeg;
-    const int32_t *v_idx_off;
-    const int32_t *v_cnt_ge;
-    const int32_t *v_var;
-    const uint16_t *v_apos;
+    const int32_t *c_pass;     // [n_cpass][2] = {max degree in pass, A offset of pass}
+    const int32_t *c_cnt_ge;   // [34] number of checks with degree >= d (zero padded)
+    const int32_t *v_pass;     // [n_vpass][2] = {max degree in pass, index-table offset of pass}
+    const int32_t *v_cnt_ge;   // [34]
+    const int32_t *v_var;      // [n_vpass*L] variable id per slot (-1 none)
+    const uint16_t *v_apos;    // [v_apos_len] A word of (pass, k, lane)
+    int32_t v_apos_len;
+    int32_t idx_lds_bytes;     // bytes of the block-shared LDS copy of v_apos (0 = read it from global)
     int32_t n_cpass, n_vpass;
     int32_t a_words, zero_pos;
     int32_t m, n, nwords;      // nwords = (n+31)/32 packed output words per frame
