@@ -1,0 +1,70 @@
+// Micro-benchmark (developer tool, not part of the product): VALU issue rates on gfx950 that the BP
+// kernel's cost model depends on.  hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
+//   1. v_fma_f32 throughput per SIMD at 1..8 waves/SIMD
+//   2. v_exp_f32 / v_log_f32 throughput
+//   3. does a wave64 VALU op with one 32-lane half fully EXEC-masked issue in half the time?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define N_ITER 4096
+
+template <int MODE>
+__global__ void k(float *out, int mask_upper) {
+    float a0 = threadIdx.x * 1e-3f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const float b = 0.999f, c = 1e-3f;
+    const bool on = !(mask_upper && (threadIdx.x & 32));
+    if (on) {
+        for (int i = 0; i < N_ITER; ++i) {
+            if (MODE == 0) {
+#define F(x) x = __builtin_fmaf(x, b, c)
+                F(a0); F(a1); F(a2); F(a3); F(a4); F(a5); F(a6); F(a7);
+#undef F
+            } else if (MODE == 1) {
+#define F(x) x = __builtin_amdgcn_exp2f(x * -0.001f)
+                F(a0); F(a1); F(a2); F(a3); F(a4); F(a5); F(a6); F(a7);
+#undef F
+            } else if (MODE == 2) {
+#define F(x) x = __builtin_amdgcn_logf(x + 2.0f)
+                F(a0); F(a1); F(a2); F(a3); F(a4); F(a5); F(a6); F(a7);
+#undef F
+            } else {  // dependent chain
+                a0 = __builtin_fmaf(a0, b, c); a0 = __builtin_fmaf(a0, b, c); a0 = __builtin_fmaf(a0, b, c); a0 = __builtin_fmaf(a0, b, c);
+                a0 = __builtin_fmaf(a0, b, c); a0 = __builtin_fmaf(a0, b, c); a0 = __builtin_fmaf(a0, b, c); a0 = __builtin_fmaf(a0, b, c);
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+template <int MODE>
+static void run(const char *name, int waves_per_simd, int mask_upper, float *d) {
+    // one block of 256 threads = 4 waves = 1 wave per SIMD of a CU; launch 256 CUs * waves_per_simd blocks
+    const int blocks = 256 * waves_per_simd;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, mask_upper);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, mask_upper);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 5;
+    const double insts_per_simd = (double) waves_per_simd * N_ITER * 8;
+    const double cyc = ms * 1e-3 * 2.4e9;
+    printf("%-10s waves/SIMD %d mask_upper %d : %.3f ms  -> %.2f cycles per wave-instruction per SIMD (at 2.4 GHz)\n", name,
+           waves_per_simd, mask_upper, ms, cyc / insts_per_simd);
+}
+
+int main() {
+    float *d;
+    hipMalloc(&d, sizeof(float) * 256 * 8 * 256);
+    for (int w : {1, 2, 4, 8}) run<0>("fma", w, 0, d);
+    for (int w : {1, 2, 4, 8}) run<1>("exp", w, 0, d);
+    for (int w : {1, 4, 8}) run<2>("log", w, 0, d);
+    for (int w : {1, 2, 4, 8}) run<3>("fma-chain", w, 0, d);
+    for (int w : {1, 4, 8}) run<0>("fma", w, 1, d);
+    for (int w : {4}) run<1>("exp", w, 1, d);
+    return 0;
+}
