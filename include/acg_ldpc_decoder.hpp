@@ -1,0 +1,186 @@
+// acg_ldpc_decoder.hpp — C++ mirror of the reference's Decoder operator interface over the C ABI.
+//
+// Same class names, constructor arguments, decode() signature and return convention as the reference:
+//   class Decoder                          algo/algo.h:6-11
+//   class BeliefPropagationDecoder(int)    algo/bp.h:208-222      name() == "BP"
+//   class QPADMMDecoder(a, mu, it, eps)    algo/qp_admm.h:180-194 name() == "QP-ADMM"
+// so experiment.h / main.cpp style callers compile unchanged against these types.
+// Header-only; link with -lacg_ldpc_hip.  The analysed graph is cached per H (pointer + content hash),
+// because the reference passes H to every call (SURVEY §8b "Inputs").
+#pragma once
+
+#include <cassert>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "acg_ldpc.h"
+
+namespace acg_ldpc {
+
+typedef std::vector<bool> TCodeword;       // utils/codeword.h:17
+typedef std::vector<TCodeword> TMatrix;    // utils/codeword.h:18
+typedef std::vector<double> TFVector;      // utils/channel.h:8
+
+class Decoder {  // algo/algo.h:6-11
+public:
+    virtual ~Decoder() {}
+    virtual std::pair<TCodeword, bool> decode(const TMatrix &H, const TFVector &channel_word, double snr) = 0;
+    virtual std::string name() const = 0;
+};
+
+class HipDecoderBase : public Decoder {
+public:
+    ~HipDecoderBase() override {
+        for (auto &kv : cache_) {
+            acg_ldpc_decoder_destroy(kv.second.dec);
+            acg_ldpc_code_destroy(kv.second.code);
+        }
+    }
+
+    std::pair<TCodeword, bool> decode(const TMatrix &H, const TFVector &channel_word, double snr) override {
+        acg_ldpc_decoder *dec = handle(H);
+        const int n = (int) H[0].size();
+        assert((int) channel_word.size() == n);
+        std::vector<uint8_t> bits((size_t) n);
+        uint8_t ok = 0;
+        int rc = acg_ldpc_decode_batch(dec, channel_word.data(), 1, snr, bits.data(), &ok, nullptr);
+        check(rc);
+        return finish(bits, ok != 0);
+    }
+
+    // batched form: Y is frames*n doubles; returns per-frame (word, flag) exactly as decode() would
+    std::vector<std::pair<TCodeword, bool>> decode_batch(const TMatrix &H, const std::vector<double> &Y, double snr) {
+        acg_ldpc_decoder *dec = handle(H);
+        const int n = (int) H[0].size();
+        const int64_t frames = (int64_t) (Y.size() / (size_t) n);
+        std::vector<uint8_t> bits((size_t) frames * n), ok((size_t) frames);
+        check(acg_ldpc_decode_batch(dec, Y.data(), frames, snr, bits.data(), ok.data(), nullptr));
+        std::vector<std::pair<TCodeword, bool>> out;
+        out.reserve((size_t) frames);
+        for (int64_t f = 0; f < frames; f++)
+            out.push_back(finish(std::vector<uint8_t>(bits.begin() + f * n, bits.begin() + (f + 1) * n), ok[f] != 0));
+        return out;
+    }
+
+    // the C handle for Monte-Carlo runs (acg_ldpc_mc_run)
+    acg_ldpc_decoder *handle(const TMatrix &H) {
+        std::lock_guard<std::mutex> lk(mu_);
+        const int m = (int) H.size(), n = (int) H[0].size();
+        std::vector<uint8_t> dense((size_t) m * n);
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j < n; j++) {
+                dense[(size_t) i * n + j] = H[i][j];
+                h = (h ^ (uint64_t) H[i][j]) * 1099511628211ull;
+            }
+        const Key key{m, n, h};
+        auto it = cache_.find(key);
+        if (it != cache_.end()) return it->second.dec;
+        Entry e{};
+        check(acg_ldpc_code_from_dense(dense.data(), m, n, &e.code));
+        acg_ldpc_params p;
+        acg_ldpc_params_default(&p);
+        fill(p);
+        check(acg_ldpc_decoder_create(e.code, &p, &e.dec));
+        cache_[key] = e;
+        return e.dec;
+    }
+
+protected:
+    virtual void fill(acg_ldpc_params &p) const = 0;
+    virtual std::pair<TCodeword, bool> finish(const std::vector<uint8_t> &bits, bool ok) const = 0;
+
+    static void check(int rc) {
+        if (rc != 0) {  // the reference aborts through assert(); so does the adaptor, with the library's message
+            std::fprintf(stderr, "acg_ldpc: error %d: %s\n", rc, acg_ldpc_last_error());
+            std::abort();
+        }
+    }
+
+private:
+    struct Key {
+        int m, n;
+        uint64_t h;
+        bool operator<(const Key &o) const { return m != o.m ? m < o.m : (n != o.n ? n < o.n : h < o.h); }
+    };
+    struct Entry {
+        acg_ldpc_code *code;
+        acg_ldpc_decoder *dec;
+    };
+    std::map<Key, Entry> cache_;
+    std::mutex mu_;
+};
+
+// algo/bp.h:208-222
+class BeliefPropagationDecoder : public HipDecoderBase {
+public:
+    explicit BeliefPropagationDecoder(int max_iter) : _max_iter(max_iter) {}
+    std::string name() const override { return "BP"; }  // bp.h:218
+
+protected:
+    void fill(acg_ldpc_params &p) const override {
+        p.algo = ACG_LDPC_BP_SUMPRODUCT;
+        p.max_iter = _max_iter;
+    }
+    std::pair<TCodeword, bool> finish(const std::vector<uint8_t> &bits, bool ok) const override {
+        if (!ok) return {TCodeword(), false};  // bp.h:198
+        return {TCodeword(bits.begin(), bits.end()), true};
+    }
+
+private:
+    int _max_iter;
+};
+
+// algo/qp_admm.h:180-194 (same defaults)
+class QPADMMDecoder : public HipDecoderBase {
+public:
+    explicit QPADMMDecoder(double alpha, double mu, int max_iter = 2000, double eps_stop = 1e-5)
+        : _alpha(alpha), _mu(mu), _eps_stop(eps_stop), _max_iter(max_iter) {}
+    std::string name() const override { return "QP-ADMM"; }  // qp_admm.h:189
+
+protected:
+    void fill(acg_ldpc_params &p) const override {
+        p.algo = ACG_LDPC_QPADMM;
+        p.max_iter = _max_iter;
+        p.alpha = _alpha;
+        p.mu = _mu;
+        p.eps_stop = _eps_stop;
+    }
+    std::pair<TCodeword, bool> finish(const std::vector<uint8_t> &bits, bool ok) const override {
+        return {TCodeword(bits.begin(), bits.end()), ok};  // qp_admm.h:112-114 (zeros,false) / :177 (word,true)
+    }
+
+private:
+    double _alpha, _mu, _eps_stop;
+    int _max_iter;
+};
+
+// build-added (north_star); not in the reference
+class MinSumDecoder : public HipDecoderBase {
+public:
+    explicit MinSumDecoder(int max_iter, double scale = 1.0) : _max_iter(max_iter), _scale(scale) {}
+    std::string name() const override { return "MS"; }
+
+protected:
+    void fill(acg_ldpc_params &p) const override {
+        p.algo = ACG_LDPC_BP_MINSUM;
+        p.max_iter = _max_iter;
+        p.ms_scale = _scale;
+    }
+    std::pair<TCodeword, bool> finish(const std::vector<uint8_t> &bits, bool ok) const override {
+        if (!ok) return {TCodeword(), false};
+        return {TCodeword(bits.begin(), bits.end()), true};
+    }
+
+private:
+    int _max_iter;
+    double _scale;
+};
+
+}  // namespace acg_ldpc
