@@ -20,7 +20,8 @@ class LdpcError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("algo", C.c_int32), ("max_iter", C.c_int32), ("alpha", C.c_double), ("mu", C.c_double),
                 ("eps_stop", C.c_double), ("ms_scale", C.c_double), ("early_exit", C.c_int32),
-                ("precision", C.c_int32), ("device", C.c_int32), ("lanes_per_frame", C.c_int32)]
+                ("precision", C.c_int32), ("device", C.c_int32), ("lanes_per_frame", C.c_int32),
+                ("engine", C.c_int32), ("reserved", C.c_int32)]
 
 
 class McCfg(C.Structure):
@@ -37,6 +38,7 @@ class McResult(C.Structure):
 ALGO_BP, ALGO_MINSUM, ALGO_QPADMM = 0, 1, 2
 PREC_DEFAULT, PREC_F64, PREC_F32 = 0, 1, 2
 NOISE_DEVICE_PHILOX, NOISE_HOST_MT19937 = 0, 1
+ENGINE_AUTO, ENGINE_FUSED, ENGINE_STREAMED = 0, 1, 2
 
 # every symbol include/acg_ldpc.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double

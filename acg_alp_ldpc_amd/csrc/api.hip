@@ -29,6 +29,13 @@ hipError_t phi_debug_launch(const void *x, void *out, int n, int f64, hipStream_
 hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t first_frame, uint64_t seed,
                        const uint32_t *cw_packed, int64_t n_cw, float sigma, hipStream_t s);
 
+const void *bp_streamed_ptr(int algo, int f64);
+hipError_t bp_streamed_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid,
+                              int block, hipStream_t s);
+hipError_t classify_launch(const float *y, const uint32_t *bits, const uint8_t *ok, const int32_t *iters, int64_t frames,
+                           int n, int nwords, int64_t first_frame, const uint32_t *cw_packed, int64_t n_cw,
+                           unsigned long long *counters, hipStream_t s);
+
 struct AdmmDevice;  // admm_kernels.hip
 AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_count, std::string &err);
 void admm_device_destroy(AdmmDevice *d);
@@ -79,6 +86,12 @@ struct acg_ldpc_decoder {
     int grid_cap[2] = {0, 0};          // [mc] resident blocks: occupancy x CUs
     const void *kernel[2] = {nullptr, nullptr};
     size_t lds_block = 0;
+    // streamed BP engine
+    bool streamed = false;
+    StreamTables stab{};
+    const void *skernel = nullptr;
+    uint32_t *sws = nullptr;
+    int sgrid = 0;
     // ADMM
     AdmmDevice *admm = nullptr;
     // staging for the host API
@@ -87,6 +100,9 @@ struct acg_ldpc_decoder {
     uint8_t *st_ok = nullptr;
     int32_t *st_iters = nullptr;
     int64_t st_frames = 0;
+    // MC through engines without an in-kernel generator (streamed): chunk buffers
+    float *mc_y = nullptr;
+    int64_t mc_frames = 0;
     // MC
     uint32_t *cw_dev = nullptr;
     int64_t cw_count = 0;
@@ -191,12 +207,66 @@ int acg_ldpc_code_is_codeword(const acg_ldpc_code *code, const uint8_t *bits) {
 }
 
 // ---------------------------------------------------------------- decoder
+static int decoder_setup_streamed(acg_ldpc_decoder *d) {
+    const Code &c = d->c;
+    if (std::max(c.max_cdeg, c.max_vdeg) > 16) {
+        set_error("node degree above 16 is not supported by the streamed BP engine");
+        return 3;
+    }
+    d->streamed = true;
+    d->f64 = (d->p.precision == ACG_LDPC_PREC_F64) ? 1 : 0;
+    d->L = 1;
+    StreamTables &t = d->stab;
+    int32_t *p32 = nullptr;
+#define UP32S(vec, field)                                      \
+    if (upload<int32_t>(vec, &p32)) return 10;                 \
+    d->dev_allocs.push_back(p32);                              \
+    t.field = p32;
+    UP32S(c.row_ptr, row_ptr)
+    UP32S(c.col_ptr, col_ptr)
+    UP32S(c.col_edge, col_edge)
+#undef UP32S
+    t.m = c.m;
+    t.n = c.n;
+    t.E = c.E;
+    t.nwords = (c.n + 31) / 32;
+    const size_t ts = d->f64 ? 8 : 4;
+    // per wavefront: M[E][64] + LLR[n][64] (T) + HB[nwords][64] (u32)
+    t.ws_words_per_wave = (int64_t) (((size_t) (c.E + c.n) * 64 * ts + (size_t) t.nwords * 64 * 4 + 255) / 256 * 64);
+    d->block = 256;
+    d->frames_per_block = 64;  // one 64-frame tile per workgroup at a time
+    const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
+    d->skernel = bp_streamed_ptr(algo, d->f64);
+    // 2 workgroups per CU (x 4 wavefronts = 8 waves/CU keep > 1 MB of 256-byte lines in flight per CU);
+    // each resident workgroup owns one slab: M[E][64] + LLR[n][64] + HB[nwords][64]
+    d->sgrid = 2 * d->cu_count;
+    const size_t ws_bytes = (size_t) d->sgrid * (size_t) t.ws_words_per_wave * 4;
+    HIP_OK(hipMalloc((void **) &d->sws, ws_bytes));
+    d->grid_cap[0] = d->grid_cap[1] = d->sgrid;
+    return 0;
+}
+
 static int decoder_setup_bp(acg_ldpc_decoder *d) {
     const Code &c = d->c;
+    if (d->p.engine != ACG_LDPC_ENGINE_AUTO && d->p.engine != ACG_LDPC_ENGINE_FUSED &&
+        d->p.engine != ACG_LDPC_ENGINE_STREAMED) {
+        set_error("unknown engine");
+        return 1;
+    }
+    if (d->p.engine == ACG_LDPC_ENGINE_STREAMED) return decoder_setup_streamed(d);
     d->maxd = std::max(c.max_cdeg, c.max_vdeg);
-    if (d->maxd > 32) {
-        set_error("node degree above 32 is not supported by the fused BP kernels");
-        return 3;
+    {
+        // does one frame fit in LDS?  (message words incl. padding at the smallest group size + LLRs)
+        const size_t ts0 = (d->p.precision == ACG_LDPC_PREC_F64) ? 8 : 4;
+        const size_t approx = ((size_t) c.E + (size_t) c.n + 64) * ts0;
+        const bool fits = d->maxd <= 32 && approx <= 150 * 1024 && (size_t) c.E + 16 * (size_t) d->maxd < 60000;
+        if (!fits) {
+            if (d->p.engine == ACG_LDPC_ENGINE_FUSED) {
+                set_error("code too large (or node degree > 32) for the fused LDS engine");
+                return 3;
+            }
+            return decoder_setup_streamed(d);
+        }
     }
     d->f64 = (d->p.precision == ACG_LDPC_PREC_F64) ? 1 : 0;
     int L = d->p.lanes_per_frame;
@@ -279,6 +349,11 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     int waves = 4;
     while (waves > 1 && per_frame * fpw * waves + t.idx_lds_bytes > 160 * 1024 / 2) waves >>= 1;
     if (per_frame * fpw * waves + t.idx_lds_bytes > 160 * 1024) {
+        if (d->p.engine == ACG_LDPC_ENGINE_AUTO) {
+            for (void *q : d->dev_allocs) (void) hipFree(q);
+            d->dev_allocs.clear();
+            return decoder_setup_streamed(d);
+        }
         set_error("frame state does not fit in LDS (160 KiB per CU)");
         return 3;
     }
@@ -366,6 +441,8 @@ void acg_ldpc_decoder_destroy(acg_ldpc_decoder *d) {
     if (d->stream) (void) hipStreamSynchronize(d->stream);
     for (void *p : d->dev_allocs) (void) hipFree(p);
     if (d->admm) admm_device_destroy(d->admm);
+    if (d->sws) (void) hipFree(d->sws);
+    if (d->mc_y) (void) hipFree(d->mc_y);
     if (d->st_y) (void) hipFree(d->st_y);
     if (d->st_bits) (void) hipFree(d->st_bits);
     if (d->st_ok) (void) hipFree(d->st_ok);
@@ -386,7 +463,7 @@ void acg_ldpc_decoder_layout(const acg_ldpc_decoder *d, int32_t *lds_bytes_per_f
         admm_device_layout(d->admm, lds_bytes_per_frame, lanes_per_frame, frames_per_block, grid_blocks);
         return;
     }
-    if (lds_bytes_per_frame) *lds_bytes_per_frame = d->tab.lds_bytes_per_frame;
+    if (lds_bytes_per_frame) *lds_bytes_per_frame = d->streamed ? 0 : d->tab.lds_bytes_per_frame;
     if (lanes_per_frame) *lanes_per_frame = d->L;
     if (frames_per_block) *frames_per_block = d->frames_per_block;
     if (grid_blocks) *grid_blocks = d->grid_cap[0];
@@ -413,6 +490,18 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
             set_error(err.empty() ? std::string("admm launch: ") + hipGetErrorString(e) : err);
             return 10;
         }
+    } else if (d->streamed) {
+        if (a.mc) {
+            set_error("internal: streamed engine has no in-kernel generator");
+            return 11;
+        }
+        // W wavefronts cooperate on a tile: 4 when there are enough tiles to fill the chip, more for small batches
+        const int64_t tiles = (a.frames + 63) / 64;
+        int W = 4;
+        while (W < 8 && tiles * W < 8 * (int64_t) d->cu_count) W <<= 1;
+        const int per_cu = (W <= 4) ? 2 : 1;
+        int grid = (int) std::min<int64_t>(tiles, (int64_t) per_cu * d->cu_count);
+        HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
     } else {
         int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
         const int mc = a.mc ? 1 : 0;
@@ -629,6 +718,53 @@ int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc
     int rc = 0;
     if (cfg->noise == ACG_LDPC_NOISE_HOST_MT19937) {
         rc = mc_run_host_noise(d, cfg, res);
+    } else if (d->streamed) {
+        // no in-kernel generator: AWGN kernel -> decode -> classify kernel, in bounded chunks, all on the device
+        std::lock_guard<std::mutex> lk(d->mu);
+        HIP_OK(hipSetDevice(d->device));
+        if ((rc = ensure_codewords(d, cfg))) return rc;
+        const int n = d->c.n, nwords = (n + 31) / 32;
+        int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(cfg->frames, (int64_t) (1ull << 31) / ((int64_t) n * 4)));
+        if (chunk > d->mc_frames) {
+            if (d->mc_y) (void) hipFree(d->mc_y);
+            d->mc_y = nullptr;
+            HIP_OK(hipMalloc((void **) &d->mc_y, (size_t) chunk * n * sizeof(float)));
+            d->mc_frames = chunk;
+        }
+        if (int rc2 = ensure_staging(d, std::min<int64_t>(chunk, std::max<int64_t>(cfg->frames, 1)))) return rc2;
+        HIP_OK(hipMemsetAsync(d->counters, 0, sizeof(unsigned long long) * MC_NCOUNTERS, d->stream));
+        const double var = std::pow(10, -(cfg->snr / 10)) / 2;
+        float kms = 0;
+        for (int64_t f0 = 0; f0 < cfg->frames; f0 += chunk) {
+            const int64_t fc = std::min(chunk, cfg->frames - f0);
+            HIP_OK(awgn_launch(d->mc_y, fc, n, nwords, cfg->first_frame + f0, cfg->seed, cfg->codewords ? d->cw_dev : nullptr,
+                               cfg->codewords ? cfg->n_codewords : 1, (float) std::sqrt(var), d->stream));
+            DecodeArgs a{};
+            a.y = d->mc_y;
+            a.y_is_f64 = 0;
+            a.frames = fc;
+            fill_channel(a, cfg->snr);
+            a.out_bits = d->st_bits;
+            a.out_ok = d->st_ok;
+            a.out_iters = d->st_iters;
+            if ((rc = launch_decode(d, a, d->stream))) return rc;
+            HIP_OK(classify_launch(d->mc_y, d->st_bits, d->st_ok, d->st_iters, fc, n, nwords, cfg->first_frame + f0,
+                                   cfg->codewords ? d->cw_dev : nullptr, cfg->codewords ? cfg->n_codewords : 1,
+                                   d->counters, d->stream));
+            HIP_OK(hipStreamSynchronize(d->stream));
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) kms += ms;
+        }
+        unsigned long long h[MC_NCOUNTERS];
+        HIP_OK(hipMemcpy(h, d->counters, sizeof(h), hipMemcpyDeviceToHost));
+        res->correct = (int64_t) h[MC_CORRECT];
+        res->pseudo = (int64_t) h[MC_PSEUDO];
+        res->total = (int64_t) h[MC_TOTAL];
+        res->sum_hamming = (int64_t) h[MC_HAM];
+        res->sum_hamming_ok = (int64_t) h[MC_HAM_OK];
+        res->sum_hamming_wrong = (int64_t) h[MC_HAM_WRONG];
+        res->sum_iters = (int64_t) h[MC_ITERS];
+        res->kernel_ms = kms;
     } else {
         std::lock_guard<std::mutex> lk(d->mu);
         HIP_OK(hipSetDevice(d->device));

@@ -26,6 +26,8 @@
 // early exit, bp.h:195-196), independently of the other groups in the wave.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace acg {
@@ -98,6 +100,59 @@ __global__ void awgn_kernel(float *y, int64_t frames, int n, int nwords, int64_t
             }
         }
     }
+}
+
+// Per-frame classification of exp() (experiment.h:109-120) for engines without an in-kernel generator:
+// one wavefront per frame; correct <=> ok and bits == sent word; raw-channel Hamming count from y.
+__global__ void classify_kernel(const float *y, const uint32_t *bits, const uint8_t *ok, const int32_t *iters,
+                                int64_t frames, int n, int nwords, int64_t first_frame, const uint32_t *cw_packed,
+                                int64_t n_cw, unsigned long long *counters) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t) gridDim.x * (blockDim.x >> 6);
+    unsigned long long c_ok = 0, c_ps = 0, c_tot = 0, c_h = 0, c_hok = 0, c_hw = 0, c_it = 0;
+    for (int64_t f = wid; f < frames; f += nw) {
+        const uint32_t *cw = cw_packed ? cw_packed + (size_t) ((first_frame + f) % n_cw) * nwords : nullptr;
+        int ham = 0;
+        for (int v = lane; v < n; v += 64) {
+            const uint32_t bit = cw ? ((cw[v >> 5] >> (v & 31)) & 1u) : 0u;
+            const float yv = y[(size_t) f * n + v];
+            ham += ((!bit && yv <= 0.0f) || (bit && yv > 0.0f)) ? 1 : 0;
+        }
+        bool neq = false;
+        for (int w = lane; w < nwords; w += 64) neq |= (bits[(size_t) f * nwords + w] != (cw ? cw[w] : 0u));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ham += __shfl_xor(ham, o, 64);
+        const bool differ = __ballot(neq) != 0ull;
+        const bool okf = ok[f] != 0;
+        const bool correct = okf && !differ;
+        c_ok += correct;
+        c_ps += (okf && differ);
+        c_tot += 1;
+        c_h += ham;
+        c_hok += correct ? ham : 0;
+        c_hw += correct ? 0 : ham;
+        c_it += iters ? iters[f] : 0;
+    }
+    if (lane == 0 && c_tot) {
+        atomicAdd(&counters[MC_CORRECT], c_ok);
+        atomicAdd(&counters[MC_PSEUDO], c_ps);
+        atomicAdd(&counters[MC_TOTAL], c_tot);
+        atomicAdd(&counters[MC_HAM], c_h);
+        atomicAdd(&counters[MC_HAM_OK], c_hok);
+        atomicAdd(&counters[MC_HAM_WRONG], c_hw);
+        atomicAdd(&counters[MC_ITERS], c_it);
+    }
+}
+
+hipError_t classify_launch(const float *y, const uint32_t *bits, const uint8_t *ok, const int32_t *iters, int64_t frames,
+                           int n, int nwords, int64_t first_frame, const uint32_t *cw_packed, int64_t n_cw,
+                           unsigned long long *counters, hipStream_t s) {
+    int grid = (int) std::min<int64_t>((frames + 3) / 4, 256 * 8);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, y, bits, ok, iters, frames, n, nwords, first_frame,
+                       cw_packed, n_cw, counters);
+    return hipGetLastError();
 }
 
 hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t first_frame, uint64_t seed,

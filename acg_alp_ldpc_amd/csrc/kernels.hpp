@@ -50,15 +50,13 @@ struct DecodeArgs {
     unsigned long long *counters;  // MC_NCOUNTERS
 };
 
-struct AdmmTables {
-    const int32_t *grp_var;   // [n_grp_pad*3] laid out [w][slot]: variable ids (or -1)
-    const uint8_t *grp_type;  // [n_grp_pad]
-    const int32_t *var_ptr;   // [n_var_pad+1]... see admm_kernels.hip
-    const int32_t *var_grp;
-    const double *inv_coef;   // filled per decoder (depends on alpha, mu)
-    int32_t n, n_var, n_grp, n_gpass, n_vpass, max_vlist;
-    int32_t nwords;
-    int32_t lds_bytes_per_frame;
+// Streamed ("HBM") BP engine: plain CSR of the Tanner graph, read through scalar loads.
+struct StreamTables {
+    const int32_t *row_ptr;   // [m+1] edges in check-major order (variables ascending)
+    const int32_t *col_ptr;   // [n+1]
+    const int32_t *col_edge;  // [E] edge ids per variable (checks ascending)
+    int32_t m, n, E, nwords;
+    int64_t ws_words_per_wave;  // workspace words (of 4 bytes) per wavefront
 };
 
 }  // namespace acg

@@ -24,12 +24,14 @@ from .code import ParityCheckMatrix
 class Decoder:
     _algo = None
 
-    def __init__(self, max_iter, early_exit=True, precision=_lib.PREC_DEFAULT, device=-1, lanes_per_frame=0):
+    def __init__(self, max_iter, early_exit=True, precision=_lib.PREC_DEFAULT, device=-1, lanes_per_frame=0,
+                 engine=_lib.ENGINE_AUTO):
         self.max_iter = int(max_iter)
         self.early_exit = bool(early_exit)
         self.precision = precision
         self.device = device
         self.lanes_per_frame = lanes_per_frame
+        self.engine = engine
         self._handles = {}  # analysed-graph cache keyed on H (SURVEY §8b "Inputs")
 
     # -- parameters -------------------------------------------------------------------------
@@ -42,6 +44,7 @@ class Decoder:
         p.precision = self.precision
         p.device = self.device
         p.lanes_per_frame = self.lanes_per_frame
+        p.engine = self.engine
         return p
 
     # -- handle cache -----------------------------------------------------------------------

@@ -93,6 +93,11 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--matrix", default=os.path.join(ROOT, "data", "H05.txt"))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per frame (0 = library default)")
+    ap.add_argument("--engine", choices=["auto", "fused", "streamed"], default="auto",
+                    help="BP engine (default auto = fused LDS-resident for H05; streamed = messages in HBM)")
+    ap.add_argument("--algo", choices=["bp", "minsum"], default="bp")
+    ap.add_argument("--synthetic", type=int, nargs=4, metavar=("M", "N", "DV", "DC"), default=None,
+                    help="use a seeded (dv,dc)-regular M x N code instead of --matrix (configs[4]: 5000 10000 3 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the early-exit side measurements")
     ap.add_argument("--cpu-frames-per-proc", type=int, default=1500)
@@ -123,15 +128,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    H = A.read_pcm(a.matrix)
+    if a.synthetic:
+        m_, n_, dv_, dc_ = a.synthetic
+        H = A.ParityCheckMatrix(A.regular_ldpc(m_, n_, dv_, dc_, seed=1))
+        a.matrix = "synthetic_%dx%d_(%d,%d)" % (m_, n_, dv_, dc_)
+        cws = np.zeros((1, n_), dtype=np.uint8)     # all-zero codeword (both decoders are symmetric)
+    else:
+        H = A.read_pcm(a.matrix)
+        G, ok = H.get_orthogonal()
+        assert ok
+        cws = A.gen_random_codewords(G, 8192, 239239239)
     n, E, F = H.n, H.E, a.frames
     nw = (n + 31) // 32
-    G, ok = H.get_orthogonal()
-    assert ok
-    cws = A.gen_random_codewords(G, 8192, 239239239)
+    eng = {"auto": A.ENGINE_AUTO, "fused": A.ENGINE_FUSED, "streamed": A.ENGINE_STREAMED}[a.engine]
 
-    dec_fixed = A.BeliefPropagationDecoder(a.iters, early_exit=False, device=local_rank, lanes_per_frame=a.lanes)
-    dec_exit = A.BeliefPropagationDecoder(a.iters, early_exit=True, device=local_rank, lanes_per_frame=a.lanes)
+    def make(early_exit):
+        if a.algo == "minsum":
+            return A.MinSumDecoder(a.iters, 0.75, early_exit=early_exit, device=local_rank, lanes_per_frame=a.lanes,
+                                   engine=eng)
+        return A.BeliefPropagationDecoder(a.iters, early_exit=early_exit, device=local_rank, lanes_per_frame=a.lanes,
+                                          engine=eng)
+
+    dec_fixed = make(False)
+    dec_exit = make(True)
 
     y = torch.empty((F, n), dtype=torch.float32, device="cuda")
     bits = torch.zeros((F, nw), dtype=torch.int32, device="cuda")
@@ -193,28 +212,35 @@ def main():
     achieved = F * bpf / (kms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    engine_name = "streamed" if dec_fixed.layout(H)["lanes_per_frame"] == 1 else "fused"
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            if tj.get("frames") == F and tj.get("iters") == a.iters and tj.get("matrix") == os.path.basename(a.matrix):
-                traffic = tj.get("hbm_bytes_per_launch")
+            for tj in json.load(open(tpath)):
+                if (tj.get("frames") == F and tj.get("iters") == a.iters and tj.get("engine") == engine_name
+                        and tj.get("matrix") == os.path.basename(a.matrix) and tj.get("algo") == a.algo):
+                    traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
         "metric": "decoded frames/sec (+ FER@SNR) for H05.txt 50-iter BP", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: %s (%dx%d, E=%d) sum-product BP, %d iterations FIXED (no early exit), "
+        "config": {"workload": "%s: %s (%dx%d, E=%d) %s, %d iterations FIXED (no early exit), "
                                "%d AWGN frames per GPU per step at Es/N0 %.1f dB, inputs/outputs resident in HBM"
-                               % (os.path.basename(a.matrix), H.m, n, E, a.iters, F, a.snr),
+                               % ("configs[4]" if a.synthetic else "configs[1]", os.path.basename(a.matrix), H.m, n, E,
+                                  "sum-product BP" if a.algo == "bp" else "min-sum(0.75) BP", a.iters, F, a.snr),
+                   "engine": "streamed (messages in HBM)" if dec_fixed.layout(H)["lanes_per_frame"] == 1
+                             else "fused (messages in LDS)",
                    "frames_per_gpu": F, "snr_db": a.snr, "iters": a.iters, "early_exit": False,
                    "sharding": "frames [r*F,(r+1)*F) per rank, no collective on the data path",
                    "layout": dec_fixed.layout(H)},
         "fer": q_fixed["fer"], "undetected_errors": q_fixed["undetected"], "mean_exit_iter": q_fixed["mean_iters"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "model": "streamed-equivalent (SURVEY 8d): %d B/frame x %d frames / %.3f ms mean kernel time; "
-                              "messages stay in LDS, so this is NOT HBM utilisation" % (bpf, F, kms),
+                     "model": ("streamed model (SURVEY 8d): %d B/frame x %d frames / %.3f ms mean kernel time; "
+                               % (bpf, F, kms)) +
+                              ("messages live in HBM: this IS the HBM figure" if dec_fixed.layout(H)["lanes_per_frame"] == 1
+                               else "streamed-EQUIVALENT only: messages stay in LDS, so this is NOT HBM utilisation"),
                      "kernel_ms": kms, "bytes_per_frame": bpf},
     }
 
@@ -234,9 +260,7 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1 only) -------------------------------------------------------------
     if world == 1 and not a.no_cpu_baseline:
-        from oracle.pyoracle import Oracle
-        Hm = Oracle().read_pcm(a.matrix)
-        out["cpu_baseline"] = cpu_baseline(Hm, cws, a.snr, a.iters, a.cpu_frames_per_proc)
+        out["cpu_baseline"] = cpu_baseline(H.dense(), cws, a.snr, a.iters, a.cpu_frames_per_proc)
     elif world == 1:
         out["cpu_baseline"] = None
 

@@ -42,6 +42,13 @@ enum {
     ACG_LDPC_PREC_F32 = 2      /* everything fp32 (QP-ADMM then matches FER only) */
 };
 
+/* BP engine selector */
+enum {
+    ACG_LDPC_ENGINE_AUTO = 0,     /* fused when a frame's messages fit in LDS, else streamed */
+    ACG_LDPC_ENGINE_FUSED = 1,    /* messages resident in LDS for the whole decode (HBM: symbols in, bits out) */
+    ACG_LDPC_ENGINE_STREAMED = 2  /* messages [edge][frame] in HBM, one lane per frame, coalesced sweeps (any code size) */
+};
+
 /* noise source for acg_ldpc_mc_run */
 enum {
     ACG_LDPC_NOISE_DEVICE_PHILOX = 0, /* counter-based, keyed on (seed, global frame, symbol): same
@@ -63,6 +70,8 @@ typedef struct acg_ldpc_params {
     int32_t precision;  /* ACG_LDPC_PREC_* */
     int32_t device;     /* HIP device ordinal; -1 = current device */
     int32_t lanes_per_frame; /* 0 = auto; otherwise 16/32/64 lanes of a wavefront cooperate on one frame */
+    int32_t engine;     /* ACG_LDPC_ENGINE_* (BP only) */
+    int32_t reserved;   /* must be 0 */
 } acg_ldpc_params;
 
 void acg_ldpc_params_default(acg_ldpc_params *p);

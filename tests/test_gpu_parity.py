@@ -326,3 +326,68 @@ def test_full_size_round_trip_properties(A, pcm):
     assert r.pseudo <= 5
     r0 = A.run_experiment(dec, None, H, 2.0, frames=F, noise="device", seed=1)  # all-zero codeword
     assert r0.total == F and abs(r0.FER() - r.FER()) < 1e-3  # decoder symmetry
+
+
+# ---------------------------------------------------------------------------------------- streamed (HBM) engine
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_streamed_engine_equals_oracle(A, oracle, matrices, pcm, prec):
+    """the one-lane-per-frame HBM engine must give the same bits / flags / exit iterations as the oracle"""
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 21, 1500)
+    for snr in (-2.0, 1.0):
+        y = oracle.transmit_frames(cws, snr, first_seed=4000)
+        ob, ook, oit = oracle.bp_decode(Hm, y, snr, 50, threads=8)
+        for ee in (True, False):
+            dec = A.BeliefPropagationDecoder(50, engine=A.ENGINE_STREAMED, early_exit=ee,
+                                             precision=A.PREC_F64 if prec == "f64" else A.PREC_DEFAULT)
+            bits, ok, iters = dec.decode_batch(H, y, snr)
+            assert dec.layout(H)["lanes_per_frame"] == 1
+            dec.close()
+            assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), (snr, ee)
+    # ragged batch (not a multiple of 64) and min-sum
+    y = oracle.transmit_frames(cws[:77], 0.0, first_seed=9)
+    ob, ook, oit = oracle.minsum_decode(Hm, y, 0.0, 30, 0.75, threads=4)
+    dec = A.MinSumDecoder(30, 0.75, engine=A.ENGINE_STREAMED, precision=A.PREC_F64)
+    bits, ok, iters = dec.decode_batch(H, y, 0.0)
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+
+
+def test_streamed_mc_matches_fused_mc(A, pcm):
+    """same Philox frames through both engines -> identical Monte-Carlo counters"""
+    H = pcm["optimalH"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 777, 5)
+    a = A.BeliefPropagationDecoder(50, engine=A.ENGINE_FUSED)
+    b = A.BeliefPropagationDecoder(50, engine=A.ENGINE_STREAMED)
+    ra = A.run_experiment(a, cws, H, -1.5, frames=30000, first_frame=123, noise="device", seed=4)
+    rb = A.run_experiment(b, cws, H, -1.5, frames=30000, first_frame=123, noise="device", seed=4)
+    assert (ra.as_vector() == rb.as_vector()).all(), (ra, rb)
+
+
+def test_config5_synthetic_regular_code(A, oracle):
+    """BASELINE configs[4]: synthetic (3,6)-regular 5000 x 10000, min-sum 50 iterations (auto -> streamed engine).
+    Oracle comparison on a few frames (fp64), size-independent properties on a larger batch."""
+    Hm = A.regular_ldpc(5000, 10000, 3, 6, seed=1)
+    H = A.ParityCheckMatrix(Hm)
+    assert (H.m, H.n, H.E) == (5000, 10000, 30000)
+    rng = np.random.default_rng(0)
+    snr = 2.0
+    sigma = np.sqrt(A.llr_variance(snr))
+    y = 1.0 + sigma * rng.standard_normal((12, 10000))      # all-zero codeword (SURVEY H7)
+    ob, ook, oit = oracle.minsum_decode(Hm, y, snr, 50, 0.75, threads=8)
+    dec64 = A.MinSumDecoder(50, 0.75, precision=A.PREC_F64)
+    bits, ok, iters = dec64.decode_batch(H, y, snr)
+    assert dec64.layout(H)["lanes_per_frame"] == 1            # streamed engine chosen automatically
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+    dec64.close()
+    # sum-product on the big code too
+    ob, ook, oit = oracle.bp_decode(Hm, y[:6], snr, 50, threads=6)
+    spa = A.BeliefPropagationDecoder(50)
+    bits, ok, iters = spa.decode_batch(H, y[:6], snr)
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+    spa.close()
+    dec = A.MinSumDecoder(50, 0.75, early_exit=False)
+    r = A.run_experiment(dec, None, H, snr, frames=4096, noise="device", seed=3)
+    assert r.total == 4096 and r.pseudo == 0 and r.correct >= 4090, r
+    assert r.sum_hamming == r.sum_hamming_ok + r.sum_hamming_wrong

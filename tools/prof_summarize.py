@@ -12,14 +12,14 @@ args = sys.argv[2] if len(sys.argv) > 2 else ""
 
 
 def find(pat):
-    r = sorted(glob.glob(os.path.join(out_dir, pat), recursive=True))
+    r = sorted(glob.glob(os.path.join(out_dir, pat), recursive=True), key=os.path.getmtime)
     return r[-1] if r else None
 
 
 summary = {"bench_args": args}
 stats = find("prof_stats/**/*kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
-main = [r for r in rows if "fused_kernel" in r["Name"]]
+main = [r for r in rows if "_fused_kernel" in r["Name"] or "_streamed_kernel" in r["Name"]]
 summary["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                             "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
                             "pct": float(r["Percentage"])} for r in rows[:6]]
@@ -46,10 +46,15 @@ if "FETCH_SIZE" in p and "WRITE_SIZE" in p and line:
     # the only large read is the input batch, F*n*4 bytes, read exactly once.
     fetch = p["FETCH_SIZE"] * 1024 * 2
     write = p["WRITE_SIZE"] * 1024
-    n = 280
-    summary["traffic"] = {"frames": F, "iters": line["config"]["iters"], "matrix": "H05.txt",
+    import re
+    n = int(re.search(r"\((\d+)x(\d+), E=", line["config"]["workload"]).group(2))
+    summary["traffic"] = {"frames": F, "iters": line["config"]["iters"],
+                          "matrix": line["config"]["workload"].split(": ")[1].split(" ")[0],
+                          "engine": "streamed" if line["config"]["layout"]["lanes_per_frame"] == 1 else "fused",
+                          "algo": "minsum" if "min-sum" in line["config"]["workload"] else "bp",
                           "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-                          "compulsory_input_bytes": F * n * 4,
+                          "compulsory_input_bytes": F * n * 4, "kernel_ms": line["roofline"]["kernel_ms"],
+                          "hbm_GBps_measured": (fetch + write) / (line["roofline"]["kernel_ms"] * 1e-3) / 1e9,
                           "algorithmic_streamed_bytes": line["roofline"]["bytes_per_frame"] * F,
                           "note": "FETCH_SIZE x2 (gfx950 half-count of wide reads), WRITE_SIZE as is; separate --pmc passes"}
 json.dump(summary, open(os.path.join(out_dir, "profile_summary.json"), "w"), indent=1)
