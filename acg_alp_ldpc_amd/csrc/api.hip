@@ -851,6 +851,68 @@ int acg_ldpc_transmit_host(const uint8_t *codewords, int64_t n_codewords, int32_
 }
 
 // ---------------------------------------------------------------- debug helpers (tests only)
+int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t frames, double snr, int32_t iters,
+                            int32_t f64, double *c2v, double *v2c_mag, double *v2c_sgn, double *post) {
+    if (!code || !y || frames < 1 || frames > 64 || iters < 1) {
+        set_error("bad argument (1..64 frames, iters >= 1)");
+        return 1;
+    }
+    acg_ldpc_params p;
+    acg_ldpc_params_default(&p);
+    p.algo = ACG_LDPC_BP_SUMPRODUCT;
+    p.max_iter = iters;
+    p.early_exit = 0;
+    p.engine = ACG_LDPC_ENGINE_STREAMED;
+    p.precision = f64 ? ACG_LDPC_PREC_F64 : ACG_LDPC_PREC_DEFAULT;
+    acg_ldpc_decoder *d = nullptr;
+    if (int rc = acg_ldpc_decoder_create(code, &p, &d)) return rc;
+    const int n = d->c.n, E = d->c.E;
+    const size_t ts = f64 ? 8 : 4;
+    void *dc = nullptr, *dv = nullptr, *dp = nullptr;
+    int rc = 0;
+    do {
+        if (hipMalloc(&dc, (size_t) E * 64 * ts) != hipSuccess || hipMalloc(&dv, (size_t) E * 64 * ts) != hipSuccess ||
+            hipMalloc(&dp, (size_t) n * 64 * ts) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
+        if ((rc = ensure_staging(d, frames))) break;
+        if (hipMemcpy(d->st_y, y, (size_t) frames * n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = 10; break; }
+        DecodeArgs a{};
+        a.y = d->st_y;
+        a.y_is_f64 = 1;
+        a.frames = frames;
+        fill_channel(a, snr);
+        a.out_bits = d->st_bits;
+        a.out_ok = d->st_ok;
+        a.out_iters = d->st_iters;
+        a.dbg_c2v = dc;
+        a.dbg_v2c = dv;
+        a.dbg_post = dp;
+        if ((rc = launch_decode(d, a, d->stream))) break;
+        if (hipStreamSynchronize(d->stream) != hipSuccess) { set_error("sync failed"); rc = 10; break; }
+        std::vector<unsigned char> hc((size_t) E * 64 * ts), hv((size_t) E * 64 * ts), hp((size_t) n * 64 * ts);
+        (void) hipMemcpy(hc.data(), dc, hc.size(), hipMemcpyDeviceToHost);
+        (void) hipMemcpy(hv.data(), dv, hv.size(), hipMemcpyDeviceToHost);
+        (void) hipMemcpy(hp.data(), dp, hp.size(), hipMemcpyDeviceToHost);
+        auto get = [&](const std::vector<unsigned char> &b, size_t idx) -> double {
+            if (f64) return reinterpret_cast<const double *>(b.data())[idx];
+            return (double) reinterpret_cast<const float *>(b.data())[idx];
+        };
+        for (int f = 0; f < frames; f++) {
+            for (int e = 0; e < E; e++) {  // edge order: check-major, variables ascending (same as the oracle's trace)
+                c2v[(size_t) f * E + e] = get(hc, (size_t) e * 64 + f);
+                const double w = get(hv, (size_t) e * 64 + f);
+                v2c_mag[(size_t) f * E + e] = std::fabs(w);  // the LSB carries the hard bit: < 1 ulp of the magnitude
+                v2c_sgn[(size_t) f * E + e] = std::signbit(w) ? -1.0 : 1.0;
+            }
+            for (int v = 0; v < n; v++) post[(size_t) f * n + v] = get(hp, (size_t) v * 64 + f);
+        }
+    } while (0);
+    if (dc) (void) hipFree(dc);
+    if (dv) (void) hipFree(dv);
+    if (dp) (void) hipFree(dp);
+    acg_ldpc_decoder_destroy(d);
+    return rc;
+}
+
 int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f64) {
     const size_t es = f64 ? 8 : 4;
     void *dx = nullptr, *dout = nullptr;

@@ -314,6 +314,10 @@ __global__ void __launch_bounds__(512) bp_streamed_kernel(const StreamTables t, 
             }
             const bool done = latched || !valid;
             if (sonly) break;
+            if (a.dbg_c2v && tile == 0 && it == a.max_iter - 1) {  // diagnostics: c->v words of the last sweep
+                T *dc = reinterpret_cast<T *>(a.dbg_c2v);
+                for (int e = w; e < t.E; e += W) dc[(size_t) e * 64 + lane] = M[(size_t) e * 64 + lane];
+            }
             if (a.early_exit && __ballot(!done) == 0ull) break;  // identical in every wave of the block
             // ---- variable sweep (bp.h:160-169) + posterior hard decisions (bp.h:191-193) ----
             for (int task = w; task < n_task; task += W) {
@@ -355,6 +359,19 @@ __global__ void __launch_bounds__(512) bp_streamed_kernel(const StreamTables t, 
                 if (!latched) HB[(size_t) task * 64 + lane] = word;  // frozen once the frame has converged
             }
             __syncthreads();
+            if (a.dbg_v2c && tile == 0 && it == a.max_iter - 1) {  // diagnostics: v->c words + posteriors
+                T *dv = reinterpret_cast<T *>(a.dbg_v2c);
+                T *dc = reinterpret_cast<T *>(a.dbg_c2v);
+                T *dp = reinterpret_cast<T *>(a.dbg_post);
+                for (int e = w; e < t.E; e += W) dv[(size_t) e * 64 + lane] = M[(size_t) e * 64 + lane];
+                for (int v = w; v < t.n; v += W) {
+                    T sum = 0;  // estimate() = llr + sum of the c->v mailbox (bp.h:85-90), from the dumped c->v words
+                    for (int k = sload(t.col_ptr, v); k < sload(t.col_ptr, v + 1); ++k)
+                        sum += dc[(size_t) sload(t.col_edge, k) * 64 + lane];
+                    dp[(size_t) v * 64 + lane] = LLR[(size_t) v * 64 + lane] + sum;
+                }
+                __syncthreads();
+            }
         }
         // ---- outputs ----
         if (valid) {

@@ -48,6 +48,11 @@ struct DecodeArgs {
     int64_t n_cw;
     float sigma;
     unsigned long long *counters;  // MC_NCOUNTERS
+    // diagnostics (streamed engine, first 64-frame tile only): raw message words after the LAST executed
+    // check sweep / variable sweep, [E][64], and posteriors [n][64]; null = off
+    void *dbg_c2v;
+    void *dbg_v2c;
+    void *dbg_post;
 };
 
 // Streamed ("HBM") BP engine: plain CSR of the Tanner graph, read through scalar loads.

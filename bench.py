@@ -39,6 +39,11 @@ def bp_bytes_per_frame(n, E, iters, b=4, b_in=4):
     return n * b_in + iters * (4 * E + n) * b + (n + 7) // 8
 
 
+def admm_bytes_per_frame(n, n_con, n_var, iters, b=8, b_in=4):
+    """B_admm = n*b_in + I*(5C + 3V)*b + ceil(n/8)"""
+    return n * b_in + iters * (5 * n_con + 3 * n_var) * b + (n + 7) // 8
+
+
 def cpu_baseline_worker(args):
     """one process = one single-threaded reference decoder (BP's global node counter forbids threads)"""
     kind, Hm, y, snr, max_iter = args
@@ -95,7 +100,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per frame (0 = library default)")
     ap.add_argument("--engine", choices=["auto", "fused", "streamed"], default="auto",
                     help="BP engine (default auto = fused LDS-resident for H05; streamed = messages in HBM)")
-    ap.add_argument("--algo", choices=["bp", "minsum"], default="bp")
+    ap.add_argument("--algo", choices=["bp", "minsum", "qpadmm"], default="bp")
+    ap.add_argument("--alpha", type=float, default=1.95)
+    ap.add_argument("--mu", type=float, default=0.5)
     ap.add_argument("--synthetic", type=int, nargs=4, metavar=("M", "N", "DV", "DC"), default=None,
                     help="use a seeded (dv,dc)-regular M x N code instead of --matrix (configs[4]: 5000 10000 3 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,6 +150,10 @@ def main():
     eng = {"auto": A.ENGINE_AUTO, "fused": A.ENGINE_FUSED, "streamed": A.ENGINE_STREAMED}[a.engine]
 
     def make(early_exit):
+        if a.algo == "qpadmm":
+            # fixed work for QP-ADMM = eps_stop 0 (the residual test never fires): every frame runs max_iter sweeps
+            return A.QPADMMDecoder(a.alpha, a.mu, a.iters, 1e-5 if early_exit else 0.0, device=local_rank,
+                                   lanes_per_frame=a.lanes)
         if a.algo == "minsum":
             return A.MinSumDecoder(a.iters, 0.75, early_exit=early_exit, device=local_rank, lanes_per_frame=a.lanes,
                                    engine=eng)
@@ -196,7 +207,7 @@ def main():
         pad = np.zeros((cws.shape[0], nw * 32), dtype=np.uint8)
         pad[:, :n] = cws
         cwp = torch.from_numpy(np.packbits(pad, axis=1, bitorder="little").view(np.int32).copy()).cuda()
-        good = (bits == cwp[idx]).all(dim=1) & (okf == 1)
+        good = (bits == cwp[idx]).all(dim=1) & (okf == 1)  # (QP-ADMM: ok is always 1; a wrong word is counted by the compare)
         v = torch.stack([good.sum(), okf.sum(), its.sum(), torch.tensor(F, device="cuda")]).to(torch.int64)
         if world > 1:
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
@@ -208,7 +219,11 @@ def main():
     dt, kms = run(dec_fixed, a.snr, a.steps, a.warmup)
     q_fixed = quality()
     value = world * F * a.steps / dt
-    bpf = bp_bytes_per_frame(n, E, a.iters)
+    if a.algo == "qpadmm":
+        sh = H.admm_shape()
+        bpf = admm_bytes_per_frame(n, sh["n_con"], sh["n_var"], a.iters)
+    else:
+        bpf = bp_bytes_per_frame(n, E, a.iters)
     achieved = F * bpf / (kms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -224,11 +239,12 @@ def main():
     out = {
         "metric": "decoded frames/sec (+ FER@SNR) for H05.txt 50-iter BP", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f64" if a.algo == "qpadmm" else "f32"), "data": "synthetic",
         "config": {"workload": "%s: %s (%dx%d, E=%d) %s, %d iterations FIXED (no early exit), "
                                "%d AWGN frames per GPU per step at Es/N0 %.1f dB, inputs/outputs resident in HBM"
                                % ("configs[4]" if a.synthetic else "configs[1]", os.path.basename(a.matrix), H.m, n, E,
-                                  "sum-product BP" if a.algo == "bp" else "min-sum(0.75) BP", a.iters, F, a.snr),
+                                  {"bp": "sum-product BP", "minsum": "min-sum(0.75) BP",
+                                   "qpadmm": "QP-ADMM(%g,%g) fp64" % (a.alpha, a.mu)}[a.algo], a.iters, F, a.snr),
                    "engine": "streamed (messages in HBM)" if dec_fixed.layout(H)["lanes_per_frame"] == 1
                              else "fused (messages in LDS)",
                    "frames_per_gpu": F, "snr_db": a.snr, "iters": a.iters, "early_exit": False,
@@ -252,7 +268,8 @@ def main():
             dte, kmse = run(dec_exit, snr, max(3, a.steps // 2), 1)
             q = quality()
             st = max(3, a.steps // 2)
-            bpf_e = bp_bytes_per_frame(n, E, q["mean_iters"])
+            bpf_e = (admm_bytes_per_frame(n, sh["n_con"], sh["n_var"], q["mean_iters"]) if a.algo == "qpadmm"
+                     else bp_bytes_per_frame(n, E, q["mean_iters"]))
             ee["%+.1fdB" % snr] = {"value": world * F * st / dte, "unit": "frames/s", "ms_per_step": dte / st * 1e3,
                                     "kernel_ms": kmse, "fer": q["fer"], "mean_iters": q["mean_iters"],
                                     "roofline_frac_streamed_equiv": F * bpf_e / (kmse * 1e-3) / 1e9 / HBM_PEAK_GBS}

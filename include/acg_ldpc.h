@@ -189,6 +189,12 @@ int acg_ldpc_awgn_dev(acg_ldpc_decoder *dec, const acg_ldpc_mc_cfg *cfg, float *
 /* diagnostics (used by tests/): evaluates the device phi(x) = -log(tanh(x/2)) (bp.h:34) of the BP kernels
  * on n host values; f64 selects the double variant. */
 int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f64);
+/* diagnostics: soft state of the device sum-product decoder after `iters` full iterations of bp.h:183-199 without
+ * the exit test, for 1..64 frames (y: frames*n doubles).  Outputs are frames*E (edge order: check-major, variables
+ * ascending) / frames*n doubles: c2v = messages check->variable, (v2c_mag, v2c_sgn) = the (phi(|x|), sign) pairs
+ * variable->check, post = VNode::estimate() (bp.h:85-90).  Runs on the streamed engine. */
+int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t frames, double snr, int32_t iters,
+                            int32_t f64, double *c2v, double *v2c_mag, double *v2c_sgn, double *post);
 
 #ifdef __cplusplus
 }

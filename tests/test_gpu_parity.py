@@ -391,3 +391,31 @@ def test_config5_synthetic_regular_code(A, oracle):
     r = A.run_experiment(dec, None, H, snr, frames=4096, noise="device", seed=3)
     assert r.total == 4096 and r.pseudo == 0 and r.correct >= 4090, r
     assert r.sum_hamming == r.sum_hamming_ok + r.sum_hamming_wrong
+
+
+@pytest.mark.parametrize("name", MATS)
+@pytest.mark.parametrize("snr", [-2.0, 2.0])
+def test_bp_soft_messages_vs_reference_trace(A, pcm, name, snr):
+    """SURVEY §8(c) stated tolerance: soft LLR-domain values after iterations 1 and 2 within
+    1e-4 * max(1, |x|) of the real reference (fp32) for finite, unsaturated (|x| < 15) values; fp64: 1e-9."""
+    g = load(name, snr)
+    H = pcm[name]
+    E = H.E
+    nf = g["trace1_c2v"].shape[0]
+    y = np.ascontiguousarray(g["y"][:nf])
+    for f64, tol in ((0, 1e-4), (1, 1e-9)):
+        for it in (1, 2):
+            c2v, mag, sgn = (np.zeros((nf, E)) for _ in range(3))
+            post = np.zeros((nf, H.n))
+            rc = A.lib().acg_ldpc_debug_bp_trace(H._h, y.ctypes.data, nf, float(snr), it, f64, c2v.ctypes.data,
+                                                 mag.ctypes.data, sgn.ctypes.data, post.ctypes.data)
+            assert rc == 0, A.lib().acg_ldpc_last_error()
+            for got, key in ((c2v, "c2v"), (post, "post")):
+                ref = g["trace%d_%s" % (it, key)]
+                m = np.isfinite(ref) & (np.abs(ref) < 15)
+                assert m.sum() > 10
+                assert (np.abs(got[m] - ref[m]) <= tol * np.maximum(1.0, np.abs(ref[m]))).all(), (name, snr, it, key, f64)
+            refm, refs = g["trace%d_v2c_mag" % it], g["trace%d_v2c_sgn" % it]
+            assert (sgn == refs).all()
+            m = np.isfinite(refm) & (refm < 15) & (refm > 1e-6)
+            assert (np.abs(mag[m] - refm[m]) <= tol * np.maximum(1.0, refm[m])).all()
