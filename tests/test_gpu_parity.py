@@ -413,9 +413,54 @@ def test_bp_soft_messages_vs_reference_trace(A, pcm, name, snr):
             for got, key in ((c2v, "c2v"), (post, "post")):
                 ref = g["trace%d_%s" % (it, key)]
                 m = np.isfinite(ref) & (np.abs(ref) < 15)
-                assert m.sum() > 10
                 assert (np.abs(got[m] - ref[m]) <= tol * np.maximum(1.0, np.abs(ref[m]))).all(), (name, snr, it, key, f64)
+                # beyond |x| = 15 (outside the SURVEY tolerance band) the values must still agree to 1e-3 relative
+                big = np.isfinite(ref) & ~m
+                assert (np.abs(got[big] - ref[big]) <= 1e-3 * np.abs(ref[big])).all()
+                assert (np.isfinite(got) == np.isfinite(ref)).all()
             refm, refs = g["trace%d_v2c_mag" % it], g["trace%d_v2c_sgn" % it]
             assert (sgn == refs).all()
             m = np.isfinite(refm) & (refm < 15) & (refm > 1e-6)
             assert (np.abs(mag[m] - refm[m]) <= tol * np.maximum(1.0, refm[m])).all()
+
+
+# ---------------------------------------------------------------------------------------- BASELINE configs 3 and 4 at size
+def test_config3_qpadmm_1m_frames_properties(A, pcm):
+    """configs[2]: H05 QP-ADMM (1.95, 0.5) 100 sweeps, eps 1e-5, 1M frames on one GPU — size-independent properties
+    (counter sums, decoder symmetry, FER inside the 99% interval of the reference's 1000-frame estimate 0.340)."""
+    from math import sqrt
+    H = pcm["H05"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 4096, 239239239)
+    dec = A.QPADMMDecoder(1.95, 0.5, 100, 1e-5)
+    F = 1 << 20
+    r = A.run_experiment(dec, cws, H, -2.0, frames=F, noise="device", seed=1)
+    assert r.total == F and r.sum_hamming == r.sum_hamming_ok + r.sum_hamming_wrong
+    p_ref = 1 - 660 / 1000.0
+    assert abs(r.FER() - p_ref) < 2.576 * sqrt(p_ref * (1 - p_ref) / 1000) + 0.005, r.FER()
+    assert 60 < r.mean_iters() <= 100
+    r0 = A.run_experiment(dec, None, H, -2.0, frames=1 << 17, noise="device", seed=1)   # all-zero word
+    assert abs(r0.FER() - r.FER()) < 0.01
+
+
+def test_config4_optimalh_qpadmm_snr_sweep_sharded(A, pcm):
+    """configs[3]: optimalH QP-ADMM (1.2, 0.55), SNR 1..4 dB, sharded exactly as 8 ranks would run it
+    (8 contiguous global ranges, counters merged on the host).  Scaled to 8 x 32k frames per point here;
+    the reference shows FER 0 at >= 1 dB with 1e4 frames, so FER must stay below 1e-3."""
+    H = pcm["optimalH"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 2048, 239239239)
+    dec = A.QPADMMDecoder(1.2, 0.55, 100, 1e-5)
+    F = 8 * 32768
+    prev = 1.0
+    for snr in (1.0, 2.0, 3.0, 4.0):
+        tot = None
+        for rank in range(8):
+            lo, cnt = A.shard_range(F, rank, 8)
+            part = A.run_experiment(dec, cws, H, snr, frames=cnt, first_frame=lo, noise="device", seed=77)
+            tot = part if tot is None else A.merge_exp_results(tot, part)
+        assert tot.total == F
+        assert tot.FER() < 1e-3 and tot.FER() <= prev + 1e-4
+        prev = tot.FER()
+    whole = A.run_experiment(dec, cws, H, 4.0, frames=F, noise="device", seed=77)
+    assert (whole.as_vector() == tot.as_vector()).all()     # same frames for 1 or 8 shards
