@@ -892,9 +892,11 @@ int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t 
         (void) hipMemcpy(hc.data(), dc, hc.size(), hipMemcpyDeviceToHost);
         (void) hipMemcpy(hv.data(), dv, hv.size(), hipMemcpyDeviceToHost);
         (void) hipMemcpy(hp.data(), dp, hp.size(), hipMemcpyDeviceToHost);
+        // the fp32 kernels work in the log2(e)-scaled message domain (bp_core.inc: Dom<float>): undo it here
+        const double unscale = f64 ? 1.0 : 0.693147180559945309;
         auto get = [&](const std::vector<unsigned char> &b, size_t idx) -> double {
             if (f64) return reinterpret_cast<const double *>(b.data())[idx];
-            return (double) reinterpret_cast<const float *>(b.data())[idx];
+            return unscale * (double) reinterpret_cast<const float *>(b.data())[idx];
         };
         for (int f = 0; f < frames; f++) {
             for (int e = 0; e < E; e++) {  // edge order: check-major, variables ascending (same as the oracle's trace)

@@ -61,7 +61,8 @@ hipError_t bp_launch(const void *kernel, const BpTables &t, const DecodeArgs &a,
 // debug / test kernels
 __global__ void phi_debug_kernel(const float *x, float *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = phi_f(x[i]);
+    // the fp32 kernels evaluate phi in the log2(e)-scaled domain: report it back in natural units
+    if (i < n) out[i] = (float) ((double) Dom<float>::phi((float) ((double) x[i] * Dom<float>::scale)) / Dom<float>::scale);
 }
 __global__ void phi_debug_kernel_f64(const double *x, double *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -48,7 +48,7 @@ struct StreamPass {
             T suf = 0;
 #pragma unroll
             for (int j = D - 1; j >= 0; --j) {
-                out[j] = phi_f(pre[j] + suf);
+                out[j] = Dom<T>::phi(pre[j] + suf);
                 suf += mag[j];
             }
         } else {
@@ -95,7 +95,7 @@ struct StreamPass {
             const T xk = llr + (pre[k] + suf);
             suf += c[k];
             const T ax = B::from(B::to(xk) & ~SIGN);
-            const T mg = (ALGO == 0) ? phi_f(ax) : ax;
+            const T mg = (ALGO == 0) ? Dom<T>::phi(ax) : ax;
             ob[k] = (B::to(mg) & ~SIGN & ~ONE) | hard | ((xk <= (T) 0) ? SIGN : (U) 0);
         }
         if (write) {
@@ -160,7 +160,7 @@ __device__ __forceinline__ typename FpBits<T>::U check_group(T *__restrict__ Mp,
                 T suf = 0;
 #pragma unroll
                 for (int j = D - 1; j >= 0; --j) {
-                    out[j] = phi_f(pre[j] + suf);
+                    out[j] = Dom<T>::phi(pre[j] + suf);
                     suf += mag[j];
                 }
             } else {
@@ -216,7 +216,7 @@ __device__ __forceinline__ uint32_t var_group(T *__restrict__ M, const T *__rest
             const T xk = llr[g] + (pre[k] + suf);
             suf += c[g][k];
             const T ax = B::from(B::to(xk) & ~B::SIGN);
-            const T mg = (ALGO == 0) ? phi_f(ax) : ax;
+            const T mg = (ALGO == 0) ? Dom<T>::phi(ax) : ax;
             const U ob = (B::to(mg) & ~B::SIGN & ~(U) 1) | hard | ((xk <= (T) 0) ? B::SIGN : (U) 0);
             M[(size_t) eid[g * D + k] * 64 + lane] = B::from(ob);
         }
@@ -264,12 +264,12 @@ __global__ void __launch_bounds__(512) bp_streamed_kernel(const StreamTables t, 
         for (int v = w; v < t.n; v += W) {
             T llr = (T) 0;
             if (valid) {
-                if (a.y_is_f64) llr = (T) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + v] / a.var);
-                else llr = (T) ((double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + v] * a.inv_var2);
+                if (a.y_is_f64) llr = (T) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + v] / a.var * Dom<T>::scale);
+                else llr = (T) ((double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + v] * (a.inv_var2 * Dom<T>::scale));
             }
             LLR[(size_t) v * 64 + lane] = llr;
             const T ax = B::from(B::to(llr) & ~B::SIGN);
-            const T mg = (ALGO == 0) ? phi_f(ax) : ax;
+            const T mg = (ALGO == 0) ? Dom<T>::phi(ax) : ax;
             const U hard = (llr <= (T) 0) ? (U) 1 : (U) 0;
             const U ob = (B::to(mg) & ~B::SIGN & ~(U) 1) | hard | ((llr <= (T) 0) ? B::SIGN : (U) 0);
             const int b = sload(t.col_ptr, v), e = sload(t.col_ptr, v + 1);
