@@ -103,12 +103,18 @@ struct AdmmDevice {
     AdmmDevTables t{};
     std::vector<void *> allocs;
     int L = 64, f32 = 0, block = 256, frames_per_block = 4, grid_cap = 256;
+    bool reg = false;  // row state in registers (ADMM_NGP variant)
+    const void *kernel[2] = {nullptr, nullptr};
     size_t lds_block = 0;
     bool guard = false;  // e_min*mu <= alpha  (qp_admm.h:108-114)
     double alpha = 0, mu = 0, eps = 0;
 };
 
-template <typename T, int L, bool MC>
+// NGP = 0: row state w in LDS (any code size).  NGP > 0 (requires n_gpass <= NGP): every lane keeps the w of its own
+// constraint groups in registers and LDS holds u_j = yl_j + mu*(z_j - b_j) instead — exactly the term the v-update
+// consumes (qp_admm.h:137), so its inner loop is one LDS read and one fma(+-1, u, B) per row (an fma with a +-1
+// multiplier rounds exactly like the reference's `B += cf * (...)`).
+template <typename T, int L, bool MC, int NGP>
 __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
                                                          const T mu, const T eps_stop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,6 +138,11 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
     unsigned int acc_correct = 0, acc_pseudo = 0, acc_total = 0;
     unsigned long long acc_ham = 0, acc_ham_ok = 0, acc_ham_wrong = 0, acc_iters = 0;
     bool converged = false;
+    T wreg[NGP > 0 ? NGP : 1][4];
+#pragma unroll
+    for (int p = 0; p < (NGP > 0 ? NGP : 1); ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wreg[p][r] = (T) 0;
 
     for (;;) {
         // ---- finish frames: residual below eps (qp_admm.h:161-163) or max_iter sweeps done ----
@@ -243,7 +254,23 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
                 if (need_init) ham = hs;
             }
             if (need_init) {
-                for (int w = l; w < 4 * t.G_pad; w += L) W[w] = (T) 0;  // z = yl = 0 (qp_admm.h:120-121)
+                if (NGP > 0) {
+                    // z = yl = 0 (qp_admm.h:120-121): w = 0 in registers, u = 0 + mu*(0 - b) in LDS
+#pragma unroll
+                    for (int p = 0; p < (NGP > 0 ? NGP : 1); ++p)
+                        if (p < t.n_gpass) {
+                            const int gs = p * L + l;
+                            const int ty = t.grp_type[gs];
+#pragma unroll
+                            for (int row = 0; row < 4; ++row) {
+                                wreg[p][row] = (T) 0;
+                                const T b = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+                                W[row * t.G_pad + gs] = (T) 0 + mu * ((T) 0 - b);
+                            }
+                        }
+                } else {
+                    for (int w = l; w < 4 * t.G_pad; w += L) W[w] = (T) 0;  // z = yl = 0 (qp_admm.h:120-121)
+                }
                 for (int w = l; w < t.V_pad; w += L) V[w] = (T) 0;
                 it = 0;
                 converged = false;
@@ -266,14 +293,19 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
                 const int ty = (int) (ent >> 22);
 #pragma unroll
                 for (int row = 0; row < 4; ++row) {
-                    const T w = W[row * t.G_pad + gs];
-                    const T z = ((T) 0 < w) ? w : (T) 0;
-                    const T nw = -w;
-                    const T yl = ((T) 0 < nw) ? nw : (T) 0;
-                    const T b = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
                     const bool plus = (ty == 3 && row == 3) || (row == wp);
-                    const T term = yl + mu * (z - b);
-                    B += plus ? term : -term;
+                    if (NGP > 0) {
+                        const T u = W[row * t.G_pad + gs];  // u_j = yl_j + mu*(z_j - b_j), stored by the row phase
+                        B = __builtin_fma(plus ? (T) 1 : (T) -1, u, B);
+                    } else {
+                        const T w = W[row * t.G_pad + gs];
+                        const T z = ((T) 0 < w) ? w : (T) 0;
+                        const T nw = -w;
+                        const T yl = ((T) 0 < nw) ? nw : (T) 0;
+                        const T b = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+                        const T term = yl + mu * (z - b);
+                        B += plus ? term : -term;
+                    }
                 }
             }
             T v = B * inv_coef[slot];
@@ -285,39 +317,84 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
         wave_sync();
         // residual, multiplier and slack update (qp_admm.h:144-159), one lane per constraint group
         T sum2 = (T) 0;
-        for (int p = 0; p < t.n_gpass; ++p) {
+        if (NGP > 0) {
+#pragma unroll
+            for (int p = 0; p < (NGP > 0 ? NGP : 1); ++p)
+                if (p < t.n_gpass) {
             const int gs = p * L + l;
-            const int ty = t.grp_type[gs];
-            T vm[3];
-            int wp[3];
-            bool have[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t e = t.grp_mem[(size_t) k * t.G_pad + gs];
-                have[k] = (e != 0xFFFFFFFFu);
-                const int id = have[k] ? (int) (e & 0xFFFFFFu) : t.n_var;  // V[n_var] is a zero cell
-                wp[k] = (int) (e >> 24);
-                vm[k] = V[id];
-            }
-            const int rows = (ty == 3) ? 4 : ty;
-#pragma unroll
-            for (int row = 0; row < 4; ++row) {
-                T r = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+                const int ty = t.grp_type[gs];
+                T vm[3];
+                int wp[3];
+                bool have[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const bool plus = (ty == 3 && row == 3) || (row == wp[k]);
-                    const T prod = plus ? vm[k] : -vm[k];
-                    r = have[k] ? (r - prod) : r;
+                    const uint32_t e = t.grp_mem[(size_t) k * t.G_pad + gs];
+                    have[k] = (e != 0xFFFFFFFFu);
+                    const int id = have[k] ? (int) (e & 0xFFFFFFu) : t.n_var;  // V[n_var] is a zero cell
+                    wp[k] = (int) (e >> 24);
+                    vm[k] = V[id];
                 }
-                const T wo = W[row * t.G_pad + gs];
-                const T nwo = -wo;
-                const T ylo = ((T) 0 < nwo) ? nwo : (T) 0;
-                const T wn = r - ylo;
-                const T z = ((T) 0 < wn) ? wn : (T) 0;
-                if (active && row < rows) {
-                    W[row * t.G_pad + gs] = wn;
-                    const T d = z - r;
-                    sum2 += d * d;
+                const int rows = (ty == 3) ? 4 : ty;
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    T r = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const bool plus = (ty == 3 && row == 3) || (row == wp[k]);
+                        const T prod = plus ? vm[k] : -vm[k];
+                        r = have[k] ? (r - prod) : r;
+                    }
+                    const T wo = wreg[p][row];
+                    const T nwo = -wo;
+                    const T ylo = ((T) 0 < nwo) ? nwo : (T) 0;
+                    const T wn = r - ylo;
+                    const T z = ((T) 0 < wn) ? wn : (T) 0;
+                    if (active && row < rows) {
+                        wreg[p][row] = wn;
+                            const T nwn = -wn;
+                            const T yln = ((T) 0 < nwn) ? nwn : (T) 0;
+                            const T bb = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+                            W[row * t.G_pad + gs] = yln + mu * (z - bb);
+                        const T d = z - r;
+                        sum2 += d * d;
+                    }
+                }
+                }
+        } else {
+            for (int p = 0; p < t.n_gpass; ++p) {
+            const int gs = p * L + l;
+                const int ty = t.grp_type[gs];
+                T vm[3];
+                int wp[3];
+                bool have[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t e = t.grp_mem[(size_t) k * t.G_pad + gs];
+                    have[k] = (e != 0xFFFFFFFFu);
+                    const int id = have[k] ? (int) (e & 0xFFFFFFu) : t.n_var;  // V[n_var] is a zero cell
+                    wp[k] = (int) (e >> 24);
+                    vm[k] = V[id];
+                }
+                const int rows = (ty == 3) ? 4 : ty;
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    T r = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const bool plus = (ty == 3 && row == 3) || (row == wp[k]);
+                        const T prod = plus ? vm[k] : -vm[k];
+                        r = have[k] ? (r - prod) : r;
+                    }
+                    const T wo = W[row * t.G_pad + gs];
+                    const T nwo = -wo;
+                    const T ylo = ((T) 0 < nwo) ? nwo : (T) 0;
+                    const T wn = r - ylo;
+                    const T z = ((T) 0 < wn) ? wn : (T) 0;
+                    if (active && row < rows) {
+                        W[row * t.G_pad + gs] = wn;
+                        const T d = z - r;
+                        sum2 += d * d;
+                    }
                 }
             }
         }
@@ -348,20 +425,22 @@ __global__ void admm_guard_kernel(DecodeArgs a, int nwords) {
     }
 }
 
-template <typename T, int L>
+constexpr int ADMM_NGP = 12;  // register-resident row state for codes with <= 12*64 constraint groups
+
+template <typename T, int L, int NGP>
 static const void *admm_ptr(bool mc) {
-    return mc ? (const void *) admm_fused_kernel<T, L, true> : (const void *) admm_fused_kernel<T, L, false>;
+    return mc ? (const void *) admm_fused_kernel<T, L, true, NGP> : (const void *) admm_fused_kernel<T, L, false, NGP>;
 }
 
-static const void *admm_kernel_ptr(int f32, int L, bool mc) {
+static const void *admm_kernel_ptr(int f32, int L, bool mc, bool reg) {
     if (f32) {
-        if (L == 64) return admm_ptr<float, 64>(mc);
-        if (L == 32) return admm_ptr<float, 32>(mc);
-        return admm_ptr<float, 16>(mc);
+        if (L == 64) return reg ? admm_ptr<float, 64, ADMM_NGP>(mc) : admm_ptr<float, 64, 0>(mc);
+        if (L == 32) return admm_ptr<float, 32, 0>(mc);
+        return admm_ptr<float, 16, 0>(mc);
     }
-    if (L == 64) return admm_ptr<double, 64>(mc);
-    if (L == 32) return admm_ptr<double, 32>(mc);
-    return admm_ptr<double, 16>(mc);
+    if (L == 64) return reg ? admm_ptr<double, 64, ADMM_NGP>(mc) : admm_ptr<double, 64, 0>(mc);
+    if (L == 32) return admm_ptr<double, 32, 0>(mc);
+    return admm_ptr<double, 16, 0>(mc);
 }
 
 template <typename T>
@@ -480,8 +559,16 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     per_frame = (per_frame + 15) & ~(size_t) 15;
     t.lds_bytes_per_frame = (int) per_frame;
     const int fpw = 64 / L;
-    int waves = 4;
-    while (waves > 1 && per_frame * fpw * waves > 160 * 1024 / 2) waves >>= 1;
+    // wavefronts per workgroup: whatever packs the most frames into the 160 KiB of a CU
+    int waves = 1, best = 0;
+    for (int w = 4; w >= 1; w >>= 1) {
+        const size_t blk = per_frame * fpw * w;
+        const int frames_cu = blk <= 160 * 1024 ? (int) ((160 * 1024) / blk) * w * fpw : 0;
+        if (frames_cu > best) {
+            best = frames_cu;
+            waves = w;
+        }
+    }
     if (per_frame * fpw * waves > 160 * 1024) {
         err = "QP-ADMM frame state does not fit in LDS (160 KiB per CU)";
         admm_device_destroy(d);
@@ -490,9 +577,11 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     d->block = waves * 64;
     d->frames_per_block = waves * fpw;
     d->lds_block = per_frame * fpw * waves;
+    d->reg = (L == 64 && t.n_gpass <= ADMM_NGP);
     int per_cu = 0;
     for (int mc = 0; mc < 2; mc++) {
-        const void *kp = admm_kernel_ptr(d->f32, L, mc != 0);
+        const void *kp = admm_kernel_ptr(d->f32, L, mc != 0, d->reg);
+        d->kernel[mc] = kp;
         if (d->lds_block > 64 * 1024 &&
             hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block) != hipSuccess) {
             err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
@@ -521,14 +610,13 @@ void admm_device_layout(const AdmmDevice *d, int *lds_per_frame, int *lanes, int
     if (grid) *grid = d->grid_cap;
 }
 
-template <typename T, int L>
-static void admm_launch_t(AdmmDevice *d, const DecodeArgs &a, int grid, hipStream_t s) {
-    if (a.mc)
-        hipLaunchKernelGGL((admm_fused_kernel<T, L, true>), dim3(grid), dim3(d->block), d->lds_block, s, d->t, a,
-                           (T) d->alpha, (T) d->mu, (T) d->eps);
-    else
-        hipLaunchKernelGGL((admm_fused_kernel<T, L, false>), dim3(grid), dim3(d->block), d->lds_block, s, d->t, a,
-                           (T) d->alpha, (T) d->mu, (T) d->eps);
+template <typename T>
+static hipError_t admm_launch_t(AdmmDevice *d, const DecodeArgs &a, int grid, hipStream_t s) {
+    AdmmDevTables tt = d->t;
+    DecodeArgs aa = a;
+    T alpha = (T) d->alpha, mu = (T) d->mu, eps = (T) d->eps;
+    void *args[5] = {&tt, &aa, &alpha, &mu, &eps};
+    return hipLaunchKernel(d->kernel[a.mc ? 1 : 0], dim3(grid), dim3(d->block), args, d->lds_block, s);
 }
 
 hipError_t admm_launch(AdmmDevice *d, const DecodeArgs &a, hipStream_t s, std::string &err) {
@@ -543,15 +631,8 @@ hipError_t admm_launch(AdmmDevice *d, const DecodeArgs &a, hipStream_t s, std::s
     }
     int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
     int grid = (int) std::min<int64_t>(blocks, d->grid_cap);
-    if (d->f32) {
-        if (d->L == 64) admm_launch_t<float, 64>(d, a, grid, s);
-        else if (d->L == 32) admm_launch_t<float, 32>(d, a, grid, s);
-        else admm_launch_t<float, 16>(d, a, grid, s);
-    } else {
-        if (d->L == 64) admm_launch_t<double, 64>(d, a, grid, s);
-        else if (d->L == 32) admm_launch_t<double, 32>(d, a, grid, s);
-        else admm_launch_t<double, 16>(d, a, grid, s);
-    }
+    const hipError_t e = d->f32 ? admm_launch_t<float>(d, a, grid, s) : admm_launch_t<double>(d, a, grid, s);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

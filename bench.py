@@ -126,11 +126,20 @@ def main():
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     if not A.device_available():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
+    # one process per GPU.  ACG_BENCH_BACKEND=gloo (+ ranks sharing a GPU) is only for rehearsing the N>1 control
+    # path on a one-GPU box; the driver's runs use nccl (= RCCL) with one GPU per rank.
+    backend = os.environ.get("ACG_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -195,7 +204,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         kms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / steps
@@ -208,7 +217,7 @@ def main():
         pad[:, :n] = cws
         cwp = torch.from_numpy(np.packbits(pad, axis=1, bitorder="little").view(np.int32).copy()).cuda()
         good = (bits == cwp[idx]).all(dim=1) & (okf == 1)  # (QP-ADMM: ok is always 1; a wrong word is counted by the compare)
-        v = torch.stack([good.sum(), okf.sum(), its.sum(), torch.tensor(F, device="cuda")]).to(torch.int64)
+        v = torch.stack([good.sum(), okf.sum(), its.sum(), torch.tensor(F, device="cuda")]).to(torch.int64).to(red_dev)
         if world > 1:
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
         c, k, i, t = (int(x) for x in v.tolist())
