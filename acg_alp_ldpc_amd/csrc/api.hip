@@ -24,7 +24,7 @@ void set_error(const std::string &msg) { g_err = msg; }
 
 hipError_t bp_launch(const void *kernel, const BpTables &t, const DecodeArgs &a, int grid, int block, size_t lds,
                      hipStream_t s);
-const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc, bool idxlds);
+const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc, int variant);
 hipError_t phi_debug_launch(const void *x, void *out, int n, int f64, hipStream_t s);
 hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t first_frame, uint64_t seed,
                        const uint32_t *cw_packed, int64_t n_cw, float sigma, hipStream_t s);
@@ -276,9 +276,10 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     }
     if (L == 0) {
         // Auto: a pass costs its largest degree for all L lanes, so finer groups waste fewer padded
-        // message slots (H05: 79% useful at L=64, 94% at L=32), but two frames then share a wavefront
-        // and an early-exiting frame waits for its partner's restart.  Measured on MI355X (H05, 50 it):
-        // fixed work 13.5 M frames/s at L=32 vs 12.4 M at L=64; early exit 38 M vs 41 M at -2 dB.
+        // message slots (H05: 79% useful at L=64, 94% at L=32); two frames then share a wavefront and an
+        // early-exiting frame waits for its partner's restart.  Measured on MI355X (H05, 50 it, LLRs in
+        // registers): fixed work 15.5 M frames/s at L=32 vs 13.2 M at L=64; early exit 43.1 M vs 42.6 M at
+        // -2 dB and 227 M vs 206 M at +2 dB.
         BpLayout l64, l32;
         if (!bp_layout_build(c, 64, l64) || !bp_layout_build(c, 32, l32)) return 3;
         auto slots = [](const BpLayout &y) {
@@ -288,7 +289,7 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
             return (double) s;
         };
         const double gain = slots(l64) / std::max(1.0, slots(l32));
-        L = (gain > (d->p.early_exit ? 1.25 : 1.05)) ? 32 : 64;
+        L = (gain > (d->p.early_exit ? 1.10 : 1.05)) ? 32 : 64;
     }
     d->L = L;
     if (!bp_layout_build(c, L, d->lay)) return 3;
@@ -297,7 +298,9 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     // the MC path stages n symbols in the message array before clearing it
     if (lay.a_words < ((c.n + 3) & ~3)) lay.a_words = (c.n + 3) & ~3;
     const size_t ts = d->f64 ? 8 : 4;
-    const int llr_words = lay.n_vpass * L;
+    // channel LLRs: in registers when there are at most 12 variable passes (degree <= 8 kernels), else in LDS
+    const bool llr_regs = (d->maxd <= 8) && (lay.n_vpass <= 12);
+    const int llr_words = llr_regs ? 0 : lay.n_vpass * L;
     size_t per_frame = (size_t) (lay.a_words + llr_words) * ts + (size_t) nwords * 4;
     per_frame = (per_frame + 15) & ~(size_t) 15;
 
@@ -332,7 +335,7 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     t.v_apos_len = lay.v_apos_len;
     // the variable-side index table is read by every wave in every iteration: keep a block-shared
     // copy in LDS unless it is large (then it is read through L1/L2)
-    const bool idxlds = (size_t) lay.v_apos_len * 2 <= 16 * 1024;
+    const bool idxlds = (size_t) lay.v_apos_len * 2 <= 16 * 1024 || llr_regs;
     t.idx_lds_bytes = idxlds ? (int) (((size_t) lay.v_apos_len * 2 + 15) & ~(size_t) 15) : 0;
     t.n_cpass = lay.n_cpass;
     t.n_vpass = lay.n_vpass;
@@ -362,7 +365,8 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     d->lds_block = per_frame * fpw * waves + t.idx_lds_bytes;
     const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
     for (int mc = 0; mc < 2; mc++) {
-        const void *kp = bp_kernel_ptr(algo, d->f64, d->maxd, L, mc != 0, idxlds);
+        const int variant = idxlds ? ((llr_regs) ? 2 : 1) : 0;
+        const void *kp = bp_kernel_ptr(algo, d->f64, d->maxd, L, mc != 0, variant);
         if (!kp) {
             set_error("no kernel instance for this configuration");
             return 3;

@@ -33,19 +33,19 @@
 namespace acg {
 #include "bp_core.inc"
 
-const void *bp_kernel_ptr_spa_f32(int maxd, int L, bool mc, bool idxlds);
-const void *bp_kernel_ptr_spa_f64(int maxd, int L, bool mc, bool idxlds);
-const void *bp_kernel_ptr_ms_f32(int maxd, int L, bool mc, bool idxlds);
-const void *bp_kernel_ptr_ms_f64(int maxd, int L, bool mc, bool idxlds);
+const void *bp_kernel_ptr_spa_f32(int maxd, int L, bool mc, int variant);
+const void *bp_kernel_ptr_spa_f64(int maxd, int L, bool mc, int variant);
+const void *bp_kernel_ptr_ms_f32(int maxd, int L, bool mc, int variant);
+const void *bp_kernel_ptr_ms_f64(int maxd, int L, bool mc, int variant);
 
 // algo: 0 sum-product, 1 min-sum; f64: 0/1
-const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc, bool idxlds) {
+const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc, int variant) {
 #ifdef ACG_FAST_BUILD
     if (f64 || algo) return nullptr;
-    return bp_kernel_ptr_spa_f32(maxd, L, mc, idxlds);
+    return bp_kernel_ptr_spa_f32(maxd, L, mc, variant);
 #else
-    if (algo == 0) return f64 ? bp_kernel_ptr_spa_f64(maxd, L, mc, idxlds) : bp_kernel_ptr_spa_f32(maxd, L, mc, idxlds);
-    return f64 ? bp_kernel_ptr_ms_f64(maxd, L, mc, idxlds) : bp_kernel_ptr_ms_f32(maxd, L, mc, idxlds);
+    if (algo == 0) return f64 ? bp_kernel_ptr_spa_f64(maxd, L, mc, variant) : bp_kernel_ptr_spa_f32(maxd, L, mc, variant);
+    return f64 ? bp_kernel_ptr_ms_f64(maxd, L, mc, variant) : bp_kernel_ptr_ms_f32(maxd, L, mc, variant);
 #endif
 }
 
