@@ -464,3 +464,54 @@ def test_config4_optimalh_qpadmm_snr_sweep_sharded(A, pcm):
         prev = tot.FER()
     whole = A.run_experiment(dec, cws, H, 4.0, frames=F, noise="device", seed=77)
     assert (whole.as_vector() == tot.as_vector()).all()     # same frames for 1 or 8 shards
+
+
+# ---------------------------------------------------------------------------------------- large parity sub-run, threads
+def test_bp_100k_frames_identical_to_oracle(A, oracle, matrices, pcm):
+    """SURVEY §8(d) config-2 parity sub-run: 10^5 frames with the reference's host noise (frame i <- mt19937(i+1))
+    over SNR in {-3,-2,-1,0}: bits, flags and exit iterations identical to the oracle on every frame."""
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 10000, 239239239)
+    dec = A.BeliefPropagationDecoder(50)
+    threads = min(16, os.cpu_count() or 1)
+    for snr, lo, cnt in ((-3.0, 0, 10000), (-2.0, 10000, 30000), (-1.0, 40000, 30000), (0.0, 70000, 30000)):
+        y = A.transmit_frames(cws, snr, first_frame=lo, frames=cnt)      # global frames lo..lo+cnt-1, codewords cycle
+        ob, ook, oit = oracle.bp_decode(Hm, y, snr, 50, threads=threads)
+        bits, ok, iters = dec.decode_batch(H, y, snr)
+        assert (ok == ook).all(), (snr, int((ok != ook).sum()))
+        assert (bits == ob).all() and (iters == oit).all(), snr
+        sent = cws[(np.arange(lo, lo + cnt)) % len(cws)]
+        fer = 1 - ((ok == 1) & (bits == sent).all(axis=1)).mean()
+        assert {-3.0: 0.45 < fer < 0.6, -2.0: 0.07 < fer < 0.11, -1.0: fer < 0.012, 0.0: fer < 0.002}[snr], (snr, fer)
+
+
+def test_one_decoder_called_from_many_threads(A, oracle, matrices, pcm):
+    """the reference calls ONE decoder object from THREADS_NUM pthreads (experiment.h:101,127-130): concurrent
+    calls on one handle must stay correct (they are serialised inside the library)."""
+    import threading
+    Hm, H = matrices["optimalH"], pcm["optimalH"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 5, 64)
+    dec = A.BeliefPropagationDecoder(30)
+    adm = A.QPADMMDecoder(1.2, 0.55, 60, 1e-5)
+    ys = [oracle.transmit_frames(cws, -1.0, first_seed=1000 * t) for t in range(8)]
+    exp_bp = [oracle.bp_decode(Hm, y, -1.0, 30, threads=2) for y in ys]
+    exp_ad = [oracle.qpadmm_decode(Hm, y, -1.0, 1.2, 0.55, 60, 1e-5, threads=2) for y in ys]
+    dec.handle(H), adm.handle(H)     # handle creation itself is done once, as in main.cpp:28-40
+    errs = []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                b, o, i = dec.decode_batch(H, ys[t], -1.0)
+                assert (b == exp_bp[t][0]).all() and (o == exp_bp[t][1]).all() and (i == exp_bp[t][2]).all()
+                b, o, i = adm.decode_batch(H, ys[t], -1.0)
+                assert (b == exp_ad[t][0]).all() and (o == exp_ad[t][1]).all()
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
