@@ -417,7 +417,7 @@ int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *pa
         d->cu_count = prop.multiProcessorCount;
         if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = 10; break; }
         if (hipEventCreate(&d->ev0) != hipSuccess || hipEventCreate(&d->ev1) != hipSuccess) { set_error("hipEventCreate failed"); rc = 10; break; }
-        if (hipMalloc((void **) &d->counters, sizeof(unsigned long long) * MC_NCOUNTERS) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
+        if (hipMalloc((void **) &d->counters, sizeof(unsigned long long) * (MC_NCOUNTERS + 1)) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
         if (params->algo == ACG_LDPC_QPADMM) {
             d->name = "QP-ADMM";  // qp_admm.h:189
             std::string err;
@@ -509,6 +509,9 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
     } else {
         int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
         const int mc = a.mc ? 1 : 0;
+        // dynamic frame hand-out: counters[MC_NCOUNTERS] is the work counter of this launch
+        a.work_counter = d->counters + MC_NCOUNTERS;
+        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
         int grid = (int) std::min<int64_t>(blocks, d->grid_cap[mc]);
         HIP_OK(bp_launch(d->kernel[mc], d->tab, a, grid, d->block, d->lds_block, s));
     }

@@ -48,6 +48,7 @@ struct DecodeArgs {
     int64_t n_cw;
     float sigma;
     unsigned long long *counters;  // MC_NCOUNTERS
+    unsigned long long *work_counter;  // fused BP: next unassigned frame (zeroed before every launch)
     // diagnostics (streamed engine, first 64-frame tile only): raw message words after the LAST executed
     // check sweep / variable sweep, [E][64], and posteriors [n][64]; null = off
     void *dbg_c2v;
