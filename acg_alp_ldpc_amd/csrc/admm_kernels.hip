@@ -121,7 +121,6 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
     constexpr int FPW = 64 / L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = lane % L, g = lane / L;
-    const int waves_per_block = blockDim.x >> 6;
     unsigned char *base = smem + (size_t) (wave * FPW + g) * t.lds_bytes_per_frame;
     T *W = reinterpret_cast<T *>(base);        // [4][G_pad]   w_j = r_j - yl_j
     T *V = W + 4 * t.G_pad;                     // [V_pad]      by variable id (+ one zero cell at n_var)
@@ -129,10 +128,11 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
     uint32_t *OB = reinterpret_cast<uint32_t *>(Q + t.n_vpass * L);
     const T *inv_coef = reinterpret_cast<const T *>(t.inv_coef);
 
-    const int64_t n_groups = (int64_t) gridDim.x * waves_per_block * FPW;
-    int64_t frame = ((int64_t) blockIdx.x * waves_per_block + wave) * FPW + g;
-    bool active = frame < a.frames;
-    bool need_init = active;
+    // dynamic frame hand-out (see bp_core.inc): chunks of CHUNK frame indices from one global counter
+    constexpr int CHUNK = 4 * FPW;
+    int64_t wnext = 0, wend = 0;
+    int64_t frame = 0;
+    bool active = false, want = true, need_init = false;
     int it = 0;
     int ham = 0;
     unsigned int acc_correct = 0, acc_pseudo = 0, acc_total = 0;
@@ -194,9 +194,30 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
                     acc_ham_wrong += correct ? 0 : ham;
                     acc_iters += it;
                 }
-                frame += n_groups;
-                active = frame < a.frames;
-                need_init = active;
+                active = false;
+                want = true;
+            }
+        }
+        unsigned long long wm = __ballot(want && l == 0);
+        while (wm != 0ull) {
+            const int leader = __builtin_ctzll(wm);
+            wm &= wm - 1ull;
+            if (wnext >= wend) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long) CHUNK);
+                const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t) base);
+                const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32));
+                wnext = (int64_t) (((unsigned long long) bhi << 32) | blo);
+                wend = wnext + CHUNK < a.frames ? wnext + CHUNK : a.frames;
+            }
+            const bool got = wnext < wend;
+            const int64_t f = wnext;
+            if (got) wnext += 1;
+            if (lane / L == leader / L) {
+                frame = f;
+                active = got;
+                need_init = got;
+                want = false;
             }
         }
         if (__ballot(active) == 0ull) break;

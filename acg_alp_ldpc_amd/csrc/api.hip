@@ -489,6 +489,8 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
     HIP_OK(hipEventRecord(d->ev0, s));
     if (d->admm) {
         std::string err;
+        a.work_counter = d->counters + MC_NCOUNTERS;
+        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
         hipError_t e = admm_launch(d->admm, a, s, err);
         if (e != hipSuccess) {
             set_error(err.empty() ? std::string("admm launch: ") + hipGetErrorString(e) : err);
