@@ -507,6 +507,8 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         while (W < 8 && tiles * W < 8 * (int64_t) d->cu_count) W <<= 1;
         const int per_cu = (W <= 4) ? 2 : 1;
         int grid = (int) std::min<int64_t>(tiles, (int64_t) per_cu * d->cu_count);
+        a.work_counter = d->counters + MC_NCOUNTERS;
+        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
         HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
     } else {
         int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;

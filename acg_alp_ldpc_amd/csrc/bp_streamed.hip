@@ -257,7 +257,14 @@ __global__ void __launch_bounds__(512) bp_streamed_kernel(const StreamTables t, 
     const int64_t n_tiles = (a.frames + 63) / 64;
     const int n_task = (t.n + 31) / 32;  // variable tasks of 32 consecutive variables = one output word
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __shared__ unsigned long long tile_lds;
+    for (;;) {
+        // dynamic tile hand-out: early exit makes tiles finish after very different numbers of sweeps
+        __syncthreads();
+        if (threadIdx.x == 0) tile_lds = atomicAdd(a.work_counter, 1ull);
+        __syncthreads();
+        const int64_t tile = (int64_t) tile_lds;
+        if (tile >= n_tiles) break;
         const int64_t frame = tile * 64 + lane;
         const bool valid = frame < a.frames;
         // ---- channel LLRs (channel.h:14-16) and the initial v->c sweep (bp.h:184: mailboxes are zero) ----
@@ -383,7 +390,6 @@ __global__ void __launch_bounds__(512) bp_streamed_kernel(const StreamTables t, 
                 for (int k = w; k < t.nwords; k += W)
                     a.out_bits[(size_t) frame * t.nwords + k] = latched ? HB[(size_t) k * 64 + lane] : 0u;  // bp.h:198
         }
-        __syncthreads();  // the slab is reused by the next tile
     }
 }
 
