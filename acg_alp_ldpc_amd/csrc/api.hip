@@ -603,10 +603,22 @@ int acg_ldpc_decode_batch(acg_ldpc_decoder *d, const double *y, int64_t frames, 
         HIP_OK(hipMemcpyAsync(ok + f0, d->st_ok, (size_t) fc, hipMemcpyDeviceToHost, d->stream));
         if (iters) HIP_OK(hipMemcpyAsync(iters + f0, d->st_iters, (size_t) fc * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
         HIP_OK(hipStreamSynchronize(d->stream));
+        // packed words -> one byte per bit, 8 bits at a time through a 256-entry table
+        static const std::vector<uint64_t> lut = [] {
+            std::vector<uint64_t> t(256);
+            for (int x = 0; x < 256; x++) {
+                uint64_t v = 0;
+                for (int k = 0; k < 8; k++) v |= (uint64_t) ((x >> k) & 1) << (8 * k);
+                t[x] = v;
+            }
+            return t;
+        }();
         for (int64_t f = 0; f < fc; f++) {
             uint8_t *b = bits + (size_t) (f0 + f) * n;
-            const uint32_t *w = &hbits[(size_t) f * nwords];
-            for (int v = 0; v < n; v++) b[v] = (w[v >> 5] >> (v & 31)) & 1u;
+            const uint8_t *w = reinterpret_cast<const uint8_t *>(&hbits[(size_t) f * nwords]);
+            int v = 0;
+            for (; v + 8 <= n; v += 8) std::memcpy(b + v, &lut[w[v >> 3]], 8);
+            for (; v < n; v++) b[v] = (w[v >> 3] >> (v & 7)) & 1u;
         }
     }
     return 0;
