@@ -283,6 +283,19 @@ def main():
                                     "kernel_ms": kmse, "fer": q["fer"], "mean_iters": q["mean_iters"],
                                     "roofline_frac_streamed_equiv": F * bpf_e / (kmse * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out["early_exit"] = ee
+        # north_star's named variant: normalised min-sum (NOT in the reference: parity unpinned)
+        if a.algo == "bp" and not a.synthetic:
+            ms = {}
+            for early, tag in ((False, "fixed"), (True, "early_exit")):
+                dms = A.MinSumDecoder(a.iters, 0.75, early_exit=early, device=local_rank, lanes_per_frame=a.lanes, engine=eng)
+                gen_noise(a.snr)
+                dtm, kmsm = run(dms, a.snr, max(3, a.steps // 2), 1)
+                q = quality()
+                st = max(3, a.steps // 2)
+                ms[tag] = {"value": world * F * st / dtm, "unit": "frames/s", "kernel_ms": kmsm, "fer": q["fer"],
+                           "mean_iters": q["mean_iters"], "snr_db": a.snr}
+                dms.close()
+            out["minsum_0.75"] = ms
 
     # ---- CPU baseline (rank 0, N = 1 only) -------------------------------------------------------------
     if world == 1 and not a.no_cpu_baseline:
