@@ -106,7 +106,7 @@ struct acg_ldpc_decoder {
     // MC
     uint32_t *cw_dev = nullptr;
     int64_t cw_count = 0;
-    const uint8_t *cw_host_key = nullptr;
+    uint64_t cw_hash = 0;
     unsigned long long *counters = nullptr;
 };
 
@@ -643,7 +643,14 @@ float acg_ldpc_decoder_last_kernel_ms(acg_ldpc_decoder *d) {
 // ---------------------------------------------------------------- Monte-Carlo
 static int ensure_codewords(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg) {
     if (!cfg->codewords || cfg->n_codewords <= 0) return 0;
-    if (d->cw_dev && d->cw_host_key == cfg->codewords && d->cw_count == cfg->n_codewords) return 0;
+    // the device copy is keyed on the CONTENT of the host array (a pointer can be recycled for different words)
+    uint64_t h = 1469598103934665603ull;
+    {
+        const uint8_t *pb = cfg->codewords;
+        const size_t nb = (size_t) cfg->n_codewords * (size_t) d->c.n;
+        for (size_t i = 0; i < nb; i++) h = (h ^ (uint64_t) (pb[i] != 0)) * 1099511628211ull;
+    }
+    if (d->cw_dev && d->cw_hash == h && d->cw_count == cfg->n_codewords) return 0;
     if (d->cw_dev) (void) hipFree(d->cw_dev);
     d->cw_dev = nullptr;
     const int n = d->c.n, nwords = (n + 31) / 32;
@@ -653,7 +660,7 @@ static int ensure_codewords(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg) {
             if (cfg->codewords[(size_t) f * n + v]) packed[(size_t) f * nwords + (v >> 5)] |= 1u << (v & 31);
     HIP_OK(hipMalloc((void **) &d->cw_dev, packed.size() * sizeof(uint32_t)));
     HIP_OK(hipMemcpy(d->cw_dev, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    d->cw_host_key = cfg->codewords;
+    d->cw_hash = h;
     d->cw_count = cfg->n_codewords;
     return 0;
 }
