@@ -104,6 +104,7 @@ struct AdmmDevice {
     std::vector<void *> allocs;
     int L = 64, f32 = 0, block = 256, frames_per_block = 4, grid_cap = 256;
     bool reg = false;  // row state in registers (ADMM_NGP variant)
+    bool blockmode = false;  // workgroup-per-frame kernel
     const void *kernel[2] = {nullptr, nullptr};
     size_t lds_block = 0;
     bool guard = false;  // e_min*mu <= alpha  (qp_admm.h:108-114)
@@ -436,6 +437,234 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Workgroup-per-frame variant: the 256 threads of a workgroup own ONE frame (requires <= 4*256 constraint groups
+// and variables).  Same arithmetic, same order of every rounding step as the wavefront variant; the LDS footprint
+// per frame is unchanged but four times as many wavefronts work on it, which is what this latency-bound sweep
+// needs (one wavefront per frame left 5 waves per CU: 1.25 per SIMD).  Row state w and the channel terms q live in
+// registers (4 passes at most), LDS holds u_j = yl_j + mu*(z_j - b_j) and v.
+constexpr int ADMM_BLK = 256;
+constexpr int ADMM_BP = 4;
+
+template <typename T, bool MC>
+__global__ void __launch_bounds__(ADMM_BLK) admm_block_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
+                                                              const T mu, const T eps_stop) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = blockDim.x;  // 128, 192 or 256 threads = one frame
+    __shared__ T red[4];
+    __shared__ unsigned long long fr_lds;
+    __shared__ int flag_lds[2];
+    __shared__ int ham_lds;
+    const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
+    T *U = reinterpret_cast<T *>(smem);  // [4][G_pad]
+    T *V = U + 4 * t.G_pad;              // [V_pad] by variable id (+ zero cell at n_var)
+    uint32_t *OB = reinterpret_cast<uint32_t *>(V + t.V_pad);
+    const T *inv_coef = reinterpret_cast<const T *>(t.inv_coef);
+    unsigned long long acc_correct = 0, acc_pseudo = 0, acc_total = 0, acc_ham = 0, acc_ham_ok = 0, acc_ham_wrong = 0, acc_iters = 0;
+    T wreg[ADMM_BP][4], qreg[ADMM_BP];
+
+    for (;;) {
+        __syncthreads();
+        if (l == 0) {
+            fr_lds = atomicAdd(a.work_counter, 1ull);  // dynamic frame hand-out
+            ham_lds = 0;
+            flag_lds[0] = 0;
+            flag_lds[1] = 0;
+        }
+        __syncthreads();
+        const int64_t frame = (int64_t) fr_lds;
+        if (frame >= a.frames) break;
+        const int64_t gf = a.first_frame + frame;
+        const uint32_t *cw = (MC && a.cw_packed) ? a.cw_packed + (size_t) (gf % a.n_cw) * t.nwords : nullptr;
+        // ---- start of a frame --------------------------------------------------------------------------------
+        if (MC) {
+            const int nq = (t.n + 3) >> 2;
+            for (int q = l; q < nq; q += L) {
+                uint32_t r[4];
+                philox((uint32_t) gf, (uint32_t) (gf >> 32), (uint32_t) q, 0u, (uint32_t) a.seed, (uint32_t) (a.seed >> 32), r);
+                float z[4];
+                box_muller(r[0], r[1], z[0], z[1]);
+                box_muller(r[2], r[3], z[2], z[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = 4 * q + e;
+                    if (v < t.n) {
+                        const uint32_t bit = cw ? ((cw[v >> 5] >> (v & 31)) & 1u) : 0u;
+                        V[v] = (T) ((bit ? -1.0f : 1.0f) + a.sigma * z[e]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        int my_ham = 0;
+#pragma unroll
+        for (int p = 0; p < ADMM_BP; ++p) {
+            qreg[p] = (T) 0;
+            if (p < t.n_vpass) {
+                const int i = t.var_of_slot[p * L + l];
+                T q = (T) 0;  // auxiliaries: q = 0 (qp_admm.h:24)
+                if (i >= 0 && i < t.n) {
+                    if (MC) {
+                        const T yv = V[i];
+                        const uint32_t bit = cw ? ((cw[i >> 5] >> (i & 31)) & 1u) : 0u;
+                        my_ham += ((!bit && yv <= (T) 0) || (bit && yv > (T) 0)) ? 1 : 0;
+                        q = (T) (2 * (double) yv / a.var);
+                    } else if (a.y_is_f64) {
+                        q = (T) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + i] / a.var);
+                    } else {
+                        q = (T) (2 * (double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + i] / a.var);
+                    }
+                }
+                qreg[p] = q;  // CalculateCoef, algo/algo.h:13-20
+            }
+        }
+        if (MC) {
+            my_ham = group_sum<64, int>(my_ham);
+            if (lane == 0) atomicAdd(&ham_lds, my_ham);
+        }
+        __syncthreads();  // staged symbols consumed
+        for (int w = l; w < t.V_pad; w += L) V[w] = (T) 0;
+#pragma unroll
+        for (int p = 0; p < ADMM_BP; ++p)
+            if (p < t.n_gpass) {
+                const int gs = p * L + l;
+                const int ty = t.grp_type[gs];
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    wreg[p][row] = (T) 0;  // z = yl = 0 (qp_admm.h:120-121)
+                    const T b = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+                    U[row * t.G_pad + gs] = (T) 0 + mu * ((T) 0 - b);
+                }
+            }
+        __syncthreads();
+        // ---- sweeps (qp_admm.h:130-164) ------------------------------------------------------------------------
+        int it = 0;
+        while (it < a.max_iter) {
+#pragma unroll
+            for (int p = 0; p < ADMM_BP; ++p)
+                if (p < t.n_vpass) {  // v-update (qp_admm.h:132-142)
+                    const int slot = p * L + l;
+                    const int ml = t.v_maxlist[p];
+                    const uint32_t *lp = t.v_list + t.v_list_off[p] + l;
+                    T B = qreg[p] + (alpha / 2);
+                    for (int k = 0; k < ml; ++k) {
+                        const uint32_t ent = lp[(size_t) k * L];
+                        const int gs = (int) (ent & 0xFFFFFu);
+                        const int wp = (int) ((ent >> 20) & 3u);
+                        const int ty = (int) (ent >> 22);
+#pragma unroll
+                        for (int row = 0; row < 4; ++row) {
+                            const bool plus = (ty == 3 && row == 3) || (row == wp);
+                            B = __builtin_fma(plus ? (T) 1 : (T) -1, U[row * t.G_pad + gs], B);
+                        }
+                    }
+                    T v = B * inv_coef[slot];
+                    v = (v < (T) 0) ? (T) 0 : v;  // std::max(v, 0.0)
+                    v = ((T) 1 < v) ? (T) 1 : v;  // std::min(v, 1.0)
+                    const int i = t.var_of_slot[slot];
+                    if (i >= 0) V[i] = v;
+                }
+            __syncthreads();
+            T sum2 = (T) 0;  // residual, multiplier and slack update (qp_admm.h:144-159)
+#pragma unroll
+            for (int p = 0; p < ADMM_BP; ++p)
+                if (p < t.n_gpass) {
+                    const int gs = p * L + l;
+                    const int ty = t.grp_type[gs];
+                    T vm[3];
+                    int wp[3];
+                    bool have[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t e = t.grp_mem[(size_t) k * t.G_pad + gs];
+                        have[k] = (e != 0xFFFFFFFFu);
+                        const int id = have[k] ? (int) (e & 0xFFFFFFu) : t.n_var;
+                        wp[k] = (int) (e >> 24);
+                        vm[k] = V[id];
+                    }
+                    const int rows = (ty == 3) ? 4 : ty;
+#pragma unroll
+                    for (int row = 0; row < 4; ++row) {
+                        T r = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const bool plus = (ty == 3 && row == 3) || (row == wp[k]);
+                            const T prod = plus ? vm[k] : -vm[k];
+                            r = have[k] ? (r - prod) : r;
+                        }
+                        const T wo = wreg[p][row];
+                        const T nwo = -wo;
+                        const T ylo = ((T) 0 < nwo) ? nwo : (T) 0;
+                        const T wn = r - ylo;
+                        const T z = ((T) 0 < wn) ? wn : (T) 0;
+                        if (row < rows) {
+                            wreg[p][row] = wn;
+                            const T nwn = -wn;
+                            const T yln = ((T) 0 < nwn) ? nwn : (T) 0;
+                            const T bb = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
+                            U[row * t.G_pad + gs] = yln + mu * (z - bb);
+                            const T d = z - r;
+                            sum2 += d * d;
+                        }
+                    }
+                }
+            sum2 = group_sum<64, T>(sum2);
+            if (lane == 0) red[wave] = sum2;
+            if (l < 4 && l >= (L >> 6)) red[l] = (T) 0;  // workgroups of fewer than 4 wavefronts
+            __syncthreads();
+            const T tot = ((red[0] + red[1]) + red[2]) + red[3];
+            it += 1;
+            if (a.early_exit && tot < eps_stop) break;  // qp_admm.h:161-163 (identical in every thread)
+        }
+        // ---- outputs (qp_admm.h:166-177) -----------------------------------------------------------------------
+        for (int w = l; w < t.nwords; w += L) OB[w] = 0u;
+        __syncthreads();
+        for (int v = l; v < t.n; v += L)
+            if (!(V[v] <= (T) 0.5)) atomicOr(&OB[v >> 5], 1u << (v & 31));
+        __syncthreads();
+        if (a.out_bits)
+            for (int w = l; w < t.nwords; w += L) a.out_bits[(size_t) frame * t.nwords + w] = OB[w];
+        if (l == 0) {
+            if (a.out_ok) a.out_ok[frame] = 1;
+            if (a.out_iters) a.out_iters[frame] = it;
+        }
+        if (MC) {
+            for (int c = l; c < t.m; c += L) {  // IsCodeword (experiment.h:111)
+                uint32_t sy = 0;
+                for (int e = t.row_ptr[c]; e < t.row_ptr[c + 1]; ++e) {
+                    const int v = t.edge_var[e];
+                    sy ^= (OB[v >> 5] >> (v & 31)) & 1u;
+                }
+                if (sy) flag_lds[0] = 1;
+            }
+            for (int w = l; w < t.nwords; w += L)
+                if (OB[w] != (cw ? cw[w] : 0u)) flag_lds[1] = 1;
+            __syncthreads();
+            if (l == 0) {
+                const bool is_cw = flag_lds[0] == 0, differ = flag_lds[1] != 0;
+                const bool correct = is_cw && !differ;
+                const int ham = ham_lds;
+                acc_correct += correct;
+                acc_pseudo += (is_cw && differ);
+                acc_total += 1;
+                acc_ham += ham;
+                acc_ham_ok += correct ? ham : 0;
+                acc_ham_wrong += correct ? 0 : ham;
+                acc_iters += it;
+            }
+        }
+    }
+    if (MC && l == 0 && acc_total) {
+        atomicAdd(&a.counters[MC_CORRECT], acc_correct);
+        atomicAdd(&a.counters[MC_PSEUDO], acc_pseudo);
+        atomicAdd(&a.counters[MC_TOTAL], acc_total);
+        atomicAdd(&a.counters[MC_HAM], acc_ham);
+        atomicAdd(&a.counters[MC_HAM_OK], acc_ham_ok);
+        atomicAdd(&a.counters[MC_HAM_WRONG], acc_ham_wrong);
+        atomicAdd(&a.counters[MC_ITERS], acc_iters);
+    }
+}
+
 // guard path (qp_admm.h:112-114): all-zero word, ok = false, no sweeps
 __global__ void admm_guard_kernel(DecodeArgs a, int nwords) {
     for (int64_t f = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; f < a.frames; f += (int64_t) gridDim.x * blockDim.x) {
@@ -488,8 +717,27 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     d->eps = p.eps_stop;
     d->f32 = (p.precision == ACG_LDPC_PREC_F32) ? 1 : 0;
     int L = p.lanes_per_frame ? p.lanes_per_frame : 64;
-    if (L != 16 && L != 32 && L != 64) {
-        err = "lanes_per_frame must be 0, 16, 32 or 64";
+    // auto / 256: one workgroup (128, 192 or 256 threads) per frame when the problem has at most 4 passes of it;
+    // the size with the fewest padded group slots wins (LDS per frame = 4 words per slot), ties go to the larger
+    const bool can_block = (A.n_grp + 1 <= ADMM_BP * ADMM_BLK) && (A.n_var <= ADMM_BP * ADMM_BLK);
+    if ((p.lanes_per_frame == 0 || p.lanes_per_frame == ADMM_BLK) && can_block) {
+        int bestL = ADMM_BLK, best_pad = ((A.n_grp + 1 + ADMM_BLK - 1) / ADMM_BLK) * ADMM_BLK;
+        for (int cand : {192, 128}) {
+            const int gp = (A.n_grp + 1 + cand - 1) / cand, vp = (A.n_var + cand - 1) / cand;
+            if (gp <= ADMM_BP && vp <= ADMM_BP && gp * cand < best_pad) {
+                best_pad = gp * cand;
+                bestL = cand;
+            }
+        }
+        L = bestL;
+        d->blockmode = true;
+    } else if (p.lanes_per_frame == ADMM_BLK) {
+        err = "lanes_per_frame = 256 needs at most 1024 constraint groups and variables";
+        delete d;
+        return nullptr;
+    }
+    if (!d->blockmode && L != 16 && L != 32 && L != 64) {
+        err = "lanes_per_frame must be 0, 16, 32, 64 (or 256 for QP-ADMM)";
         delete d;
         return nullptr;
     }
@@ -576,9 +824,37 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         return nullptr;
     }
     const size_t ts = d->f32 ? 4 : 8;
-    size_t per_frame = (size_t) (4 * t.G_pad + t.V_pad + t.n_vpass * L) * ts + (size_t) t.nwords * 4;
+    size_t per_frame = (size_t) (4 * t.G_pad + t.V_pad + (d->blockmode ? 0 : t.n_vpass * L)) * ts + (size_t) t.nwords * 4;
     per_frame = (per_frame + 15) & ~(size_t) 15;
     t.lds_bytes_per_frame = (int) per_frame;
+    if (d->blockmode) {
+        d->block = L;
+        d->frames_per_block = 1;
+        d->lds_block = per_frame;
+        if (per_frame > 160 * 1024) {
+            err = "QP-ADMM frame state does not fit in LDS (160 KiB per CU)";
+            admm_device_destroy(d);
+            return nullptr;
+        }
+        int per_cu = 0;
+        for (int mc = 0; mc < 2; mc++) {
+            const void *kp = d->f32 ? (mc ? (const void *) admm_block_kernel<float, true> : (const void *) admm_block_kernel<float, false>)
+                                    : (mc ? (const void *) admm_block_kernel<double, true> : (const void *) admm_block_kernel<double, false>);
+            d->kernel[mc] = kp;
+            if (d->lds_block > 64 * 1024 &&
+                hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block) != hipSuccess) {
+                err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+                admm_device_destroy(d);
+                return nullptr;
+            }
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, d->block, d->lds_block) != hipSuccess) occ = 1;
+            if (occ < 1) occ = 1;
+            per_cu = (mc == 0) ? occ : std::max(per_cu, occ);  // frames are handed out dynamically: a generous grid is safe
+        }
+        d->grid_cap = per_cu * cu_count;
+        return d;
+    }
     const int fpw = 64 / L;
     // wavefronts per workgroup: whatever packs the most frames into the 160 KiB of a CU
     int waves = 1, best = 0;

@@ -155,7 +155,7 @@ def test_qpadmm_golden_hard_decisions(A, pcm, name, snr):
             assert (bits == unpack(g["admm%d_%s_bits" % (it, tag)], H.n)).all(), (name, snr, it, tag)
 
 
-@pytest.mark.parametrize("lpf", [16, 32, 64])
+@pytest.mark.parametrize("lpf", [0, 16, 32, 64])   # 0 = auto = one 256-thread workgroup per frame
 def test_qpadmm_vs_oracle_iters(A, oracle, matrices, pcm, lpf):
     Hm, H = matrices["H05"], pcm["H05"]
     G, _ = oracle.get_orthogonal(Hm)
