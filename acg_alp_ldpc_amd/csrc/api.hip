@@ -29,6 +29,7 @@ hipError_t phi_debug_launch(const void *x, void *out, int n, int f64, hipStream_
 hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t first_frame, uint64_t seed,
                        const uint32_t *cw_packed, int64_t n_cw, float sigma, hipStream_t s);
 
+const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds);
 const void *bp_streamed_ptr(int algo, int f64);
 hipError_t bp_streamed_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid,
                               int block, hipStream_t s);
@@ -258,7 +259,8 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     {
         // does one frame fit in LDS?  (message words incl. padding at the smallest group size + LLRs)
         const size_t ts0 = (d->p.precision == ACG_LDPC_PREC_F64) ? 8 : 4;
-        const size_t approx = ((size_t) c.E + (size_t) c.n + 64) * ts0;
+        // (LLRs sit in registers for up to 12 passes of the group size, i.e. n <= 12288 in workgroup mode)
+        const size_t approx = ((size_t) c.E + 64 + ((size_t) c.n > 12 * 1024 ? (size_t) c.n : 0)) * ts0;
         const bool fits = d->maxd <= 32 && approx <= 150 * 1024 && (size_t) c.E + 16 * (size_t) d->maxd < 60000;
         if (!fits) {
             if (d->p.engine == ACG_LDPC_ENGINE_FUSED) {
@@ -270,8 +272,27 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     }
     d->f64 = (d->p.precision == ACG_LDPC_PREC_F64) ? 1 : 0;
     int L = d->p.lanes_per_frame;
-    if (L != 0 && L != 16 && L != 32 && L != 64) {
-        set_error("lanes_per_frame must be 0, 16, 32 or 64");
+    if (L != 0 && L != 16 && L != 32 && L != 64 && L != 256 && L != 1024) {
+        set_error("lanes_per_frame must be 0, 16, 32, 64 (wavefront groups) or 256, 1024 (one workgroup per frame)");
+        return 3;
+    }
+    // Workgroup-per-frame mode (bp_block.hip) for codes whose message array leaves room for only a few
+    // wavefront-sized frames per CU: the same LDS then feeds 4-16x as many wavefronts.
+    bool blockmode = (L == 256 || L == 1024);
+    if (L == 0 && d->maxd <= 8) {
+        const size_t ts0 = d->f64 ? 8 : 4;
+        const size_t wave_frame = ((size_t) c.E + 64 + ((size_t) c.n > 12 * 64 ? (size_t) c.n : 0)) * ts0;  // rough, L = 64
+        const int waves_cu = (int) std::min<size_t>(32, (160 * 1024) / std::max<size_t>(wave_frame, 1));
+        if (waves_cu < 12) {
+            // smallest workgroup that reaches >= 12 wavefronts per CU, else the largest
+            const size_t blk_frame = ((size_t) c.E * 5 / 4 + 256) * ts0;
+            L = (((160 * 1024) / std::max<size_t>(blk_frame, 1)) * 4 >= 12 && c.n <= 12 * 256) ? 256 : 1024;
+            blockmode = (c.n <= 12 * L);
+            if (!blockmode) L = 0;
+        }
+    }
+    if (blockmode && (d->maxd > 8 || c.n > 12 * L)) {
+        set_error("workgroup-per-frame BP needs node degree <= 8 and n <= 12 * lanes_per_frame");
         return 3;
     }
     if (L == 0) {
@@ -299,7 +320,7 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     if (lay.a_words < ((c.n + 3) & ~3)) lay.a_words = (c.n + 3) & ~3;
     const size_t ts = d->f64 ? 8 : 4;
     // channel LLRs: in registers when there are at most 12 variable passes (degree <= 8 kernels), else in LDS
-    const bool llr_regs = (d->maxd <= 8) && (lay.n_vpass <= 12);
+    const bool llr_regs = blockmode || ((d->maxd <= 8) && (lay.n_vpass <= 12));
     const int llr_words = llr_regs ? 0 : lay.n_vpass * L;
     size_t per_frame = (size_t) (lay.a_words + llr_words) * ts + (size_t) nwords * 4;
     per_frame = (per_frame + 15) & ~(size_t) 15;
@@ -335,7 +356,9 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     t.v_apos_len = lay.v_apos_len;
     // the variable-side index table is read by every wave in every iteration: keep a block-shared
     // copy in LDS unless it is large (then it is read through L1/L2)
-    const bool idxlds = (size_t) lay.v_apos_len * 2 <= 16 * 1024 || llr_regs;
+    bool idxlds = (size_t) lay.v_apos_len * 2 <= 16 * 1024 || (llr_regs && !blockmode);
+    if (blockmode) idxlds = (size_t) lay.v_apos_len * 2 <= 32 * 1024 &&
+                            (((size_t) lay.v_apos_len * 2 + 15) & ~(size_t) 15) + per_frame <= 158 * 1024;
     t.idx_lds_bytes = idxlds ? (int) (((size_t) lay.v_apos_len * 2 + 15) & ~(size_t) 15) : 0;
     t.n_cpass = lay.n_cpass;
     t.n_vpass = lay.n_vpass;
@@ -347,6 +370,36 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     t.llr_words = llr_words;
     t.lds_bytes_per_frame = (int) per_frame;
 
+    if (blockmode) {
+        if (per_frame + t.idx_lds_bytes > 160 * 1024) {
+            if (d->p.engine == ACG_LDPC_ENGINE_AUTO && d->p.lanes_per_frame == 0) {
+                for (void *q : d->dev_allocs) (void) hipFree(q);
+                d->dev_allocs.clear();
+                return decoder_setup_streamed(d);
+            }
+            set_error("frame state does not fit in LDS (160 KiB per CU)");
+            return 3;
+        }
+        d->block = L;
+        d->frames_per_block = 1;
+        d->lds_block = per_frame + t.idx_lds_bytes;
+        const int algo_b = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
+        for (int mc = 0; mc < 2; mc++) {
+            const void *kp = bp_block_kernel_ptr(algo_b, d->f64, L, mc != 0, idxlds);
+            if (!kp) {
+                set_error("no workgroup-per-frame kernel instance for this configuration");
+                return 3;
+            }
+            if (d->lds_block > 64 * 1024)
+                HIP_OK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block));
+            int occ = 0;
+            HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, d->block, d->lds_block));
+            if (occ < 1) occ = 1;
+            d->kernel[mc] = kp;
+            d->grid_cap[mc] = occ * d->cu_count;
+        }
+        return 0;
+    }
     const int fpw = 64 / L;
     // waves per block: as many as fit in half the LDS (so at least two blocks share a CU), at most 4
     int waves = 4;

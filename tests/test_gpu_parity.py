@@ -366,8 +366,9 @@ def test_streamed_mc_matches_fused_mc(A, pcm):
 
 
 def test_config5_synthetic_regular_code(A, oracle):
-    """BASELINE configs[4]: synthetic (3,6)-regular 5000 x 10000, min-sum 50 iterations (auto -> streamed engine).
-    Oracle comparison on a few frames (fp64), size-independent properties on a larger batch."""
+    """BASELINE configs[4]: synthetic (3,6)-regular 5000 x 10000, min-sum 50 iterations.  fp64 does not fit in LDS
+    (auto -> streamed engine); fp32 does, with one 1024-thread workgroup per frame.
+    Oracle comparison on a few frames, size-independent properties on a larger batch."""
     Hm = A.regular_ldpc(5000, 10000, 3, 6, seed=1)
     H = A.ParityCheckMatrix(Hm)
     assert (H.m, H.n, H.E) == (5000, 10000, 30000)
@@ -385,8 +386,13 @@ def test_config5_synthetic_regular_code(A, oracle):
     ob, ook, oit = oracle.bp_decode(Hm, y[:6], snr, 50, threads=6)
     spa = A.BeliefPropagationDecoder(50)
     bits, ok, iters = spa.decode_batch(H, y[:6], snr)
+    assert spa.layout(H)["lanes_per_frame"] == 1024       # fused, one workgroup per frame (120 KB of messages in LDS)
     assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
     spa.close()
+    sps = A.BeliefPropagationDecoder(50, engine=A.ENGINE_STREAMED)
+    bits, ok, iters = sps.decode_batch(H, y[:6], snr)
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+    sps.close()
     dec = A.MinSumDecoder(50, 0.75, early_exit=False)
     r = A.run_experiment(dec, None, H, snr, frames=4096, noise="device", seed=3)
     assert r.total == 4096 and r.pseudo == 0 and r.correct >= 4090, r
@@ -515,3 +521,45 @@ def test_one_decoder_called_from_many_threads(A, oracle, matrices, pcm):
     [x.start() for x in th]
     [x.join() for x in th]
     assert not errs, errs
+
+
+# ---------------------------------------------------------------------------------------- workgroup-per-frame fused BP
+@pytest.mark.parametrize("lpf", [256, 1024])
+def test_block_mode_equals_oracle_on_h05(A, oracle, matrices, pcm, lpf):
+    """one workgroup (256 / 1024 threads) per frame: same sweeps, same results"""
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 33, 600)
+    for snr in (-2.0, 3.0):
+        y = oracle.transmit_frames(cws, snr, first_seed=8000)
+        ob, ook, oit = oracle.bp_decode(Hm, y, snr, 50, threads=8)
+        for ee in (True, False):
+            dec = A.BeliefPropagationDecoder(50, lanes_per_frame=lpf, early_exit=ee)
+            bits, ok, iters = dec.decode_batch(H, y, snr)
+            assert dec.layout(H)["lanes_per_frame"] == lpf
+            dec.close()
+            assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), (lpf, snr, ee)
+    # Monte-Carlo path: same Philox frames as the wavefront kernels -> identical counters
+    a = A.BeliefPropagationDecoder(50, lanes_per_frame=64)
+    b = A.BeliefPropagationDecoder(50, lanes_per_frame=lpf)
+    ra = A.run_experiment(a, cws, H, -1.5, frames=20000, first_frame=7, noise="device", seed=9)
+    rb = A.run_experiment(b, cws, H, -1.5, frames=20000, first_frame=7, noise="device", seed=9)
+    assert (ra.as_vector() == rb.as_vector()).all()
+
+
+def test_block_mode_auto_for_mid_size_code(A, oracle):
+    """a 1500 x 3000 (3,6) code (E = 9000: 36 KB of messages per frame) is decoded by the workgroup-per-frame kernel"""
+    Hm = A.regular_ldpc(1500, 3000, 3, 6, seed=5)
+    H = A.ParityCheckMatrix(Hm)
+    rng = np.random.default_rng(1)
+    snr = 1.0
+    y = 1.0 + np.sqrt(A.llr_variance(snr)) * rng.standard_normal((96, 3000))
+    ob, ook, oit = oracle.bp_decode(Hm, y, snr, 40, threads=8)
+    dec = A.BeliefPropagationDecoder(40)
+    bits, ok, iters = dec.decode_batch(H, y, snr)
+    assert dec.layout(H)["lanes_per_frame"] == 256
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+    ms = A.MinSumDecoder(40, 0.75, precision=A.PREC_F64, lanes_per_frame=256)
+    ob, ook, oit = oracle.minsum_decode(Hm, y, snr, 40, 0.75, threads=8)
+    bits, ok, iters = ms.decode_batch(H, y, snr)
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
