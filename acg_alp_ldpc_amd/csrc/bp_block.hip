@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
         bool latched = false;
         for (;;) {
             const bool bad = __syncthreads_or(core.syndrome_bad() ? 1 : 0) != 0;
-            const bool conv = it > 0 && !bad;  // bp.h:195
+            const bool conv = it > 0 && it <= a.max_iter && !bad;  // bp.h:195 (max_iter = 0: never)
             const bool out_now = conv && !latched;
             const bool finish = (a.early_exit && conv) || it >= a.max_iter;
             const bool fail_now = finish && !conv && !latched;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                     for (int w = l; w < t.nwords; w += L) a.out_bits[(size_t) frame * t.nwords + w] = OB[w];
                 if (l == 0) {
                     if (a.out_ok) a.out_ok[frame] = out_now ? 1 : 0;
-                    if (a.out_iters) a.out_iters[frame] = it;
+                    if (a.out_iters) a.out_iters[frame] = it < a.max_iter ? it : a.max_iter;
                 }
                 if (MC) {
                     bool neq = false;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                         acc_ham += ham;
                         acc_ham_ok += correct ? ham : 0;
                         acc_ham_wrong += correct ? 0 : ham;
-                        acc_iters += it;
+                        acc_iters += it < a.max_iter ? it : a.max_iter;
                     }
                 }
                 latched = true;

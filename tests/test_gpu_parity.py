@@ -563,3 +563,52 @@ def test_block_mode_auto_for_mid_size_code(A, oracle):
     ob, ook, oit = oracle.minsum_decode(Hm, y, snr, 40, 0.75, threads=8)
     bits, ok, iters = ms.decode_batch(H, y, snr)
     assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+
+
+# ---------------------------------------------------------------------------------------- wide nodes, odd sizes
+@pytest.mark.parametrize("dv,dc,m,n", [(4, 16, 100, 400), (4, 32, 50, 400), (3, 12, 75, 300)])
+def test_high_degree_codes_all_engines(A, oracle, dv, dc, m, n):
+    """check degree 12 / 16 / 32: the rolled (degree > 8) sweeps of the fused kernels and the streamed engine"""
+    Hm = A.regular_ldpc(m, n, dv, dc, seed=11)
+    H = A.ParityCheckMatrix(Hm)
+    rng = np.random.default_rng(dc)
+    snr = 4.0
+    y = 1.0 + np.sqrt(A.llr_variance(snr)) * rng.standard_normal((300, n))
+    ob, ook, oit = oracle.bp_decode(Hm, y, snr, 25, threads=8)
+    mb, mok, mit = oracle.minsum_decode(Hm, y, snr, 25, 0.8, threads=8)
+    engines = [A.ENGINE_FUSED] + ([A.ENGINE_STREAMED] if dc <= 16 else [])
+    for eng in engines:
+        for lpf in ((0, 16, 32) if eng == A.ENGINE_FUSED else (0,)):
+            dec = A.BeliefPropagationDecoder(25, engine=eng, lanes_per_frame=lpf)
+            bits, ok, iters = dec.decode_batch(H, y, snr)
+            dec.close()
+            assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), (eng, lpf)
+        ms = A.MinSumDecoder(25, 0.8, engine=eng, precision=A.PREC_F64)
+        bits, ok, iters = ms.decode_batch(H, y, snr)
+        ms.close()
+        assert (ok == mok).all() and (bits == mb).all() and (iters == mit).all(), eng
+    if dc > 16:
+        with pytest.raises(A.LdpcError):
+            A.BeliefPropagationDecoder(5, engine=A.ENGINE_STREAMED).decode_batch(H, y[:2], snr)
+    assert ook.mean() > 0.5
+
+
+def test_odd_sizes_and_iteration_limits(A, oracle, matrices, pcm):
+    """n not a multiple of 32, one frame, fewer frames than lanes, max_iter 0 and 1"""
+    Hm = A.regular_ldpc(45, 75, 3, 5, seed=2)        # n = 75
+    H = A.ParityCheckMatrix(Hm)
+    rng = np.random.default_rng(4)
+    y = 1.0 + 0.7 * rng.standard_normal((5, 75))
+    for it in (0, 1, 2, 30):
+        ob, ook, oit = oracle.bp_decode(Hm, y, 1.0, it, threads=2)
+        for eng in (A.ENGINE_FUSED, A.ENGINE_STREAMED):
+            for frames in (1, 5):
+                dec = A.BeliefPropagationDecoder(it, engine=eng)
+                bits, ok, iters = dec.decode_batch(H, y[:frames], 1.0)
+                dec.close()
+                assert (ok == ook[:frames]).all() and (bits == ob[:frames]).all() and (iters == oit[:frames]).all(), (it, eng, frames)
+    Hb, H5 = matrices["H05"], pcm["H05"]
+    yy = 1.0 + 0.8 * rng.standard_normal((3, H5.n))
+    ob, ook, oit = oracle.qpadmm_decode(Hb, yy, 0.0, 1.95, 0.5, 1, 1e-5)
+    bits, ok, iters = A.QPADMMDecoder(1.95, 0.5, 1, 1e-5).decode_batch(H5, yy, 0.0)
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
