@@ -245,6 +245,26 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # The fused engine is bound by VALU issue, not by HBM: price it against that too.  Instruction counts per launch
+    # come from the committed rocprofv3 PMC pass of this exact configuration (they do not change with the clock);
+    # issue cost 2 cycles per wave64 VALU op, 12 per transcendental (tools/microbench/valu_rates.hip), 1024 SIMDs.
+    valu = None
+    try:
+        for pf in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+            if not pf.endswith("_summary.json"):
+                continue
+            pj = json.load(open(os.path.join(ROOT, "profiles", pf)))
+            tj = pj.get("traffic", {})
+            if (tj.get("frames") == F and tj.get("iters") == a.iters and tj.get("engine") == engine_name
+                    and tj.get("matrix") == os.path.basename(a.matrix) and tj.get("algo") == a.algo):
+                pm = pj["pmc_mean_per_launch"]
+                nv, nt = pm["SQ_INSTS_VALU"], pm.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+                clk = pm["GRBM_GUI_ACTIVE"] / 8 / (pj["kernel_stats"][0]["avg_ms"] * 1e-3)
+                busy = ((nv - nt) * 2 + nt * 12) / 1024
+                valu = {"issue_cycles_per_simd_per_launch": busy, "shader_clock_hz": clk,
+                        "frac_of_valu_issue_capacity": busy / (clk * kms * 1e-3), "source": "profiles/" + pf}
+    except Exception:
+        valu = None
     out = {
         "metric": "decoded frames/sec (+ FER@SNR) for H05.txt 50-iter BP", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -266,7 +286,7 @@ def main():
                                % (bpf, F, kms)) +
                               ("messages live in HBM: this IS the HBM figure" if dec_fixed.layout(H)["lanes_per_frame"] == 1
                                else "streamed-EQUIVALENT only: messages stay in LDS, so this is NOT HBM utilisation"),
-                     "kernel_ms": kms, "bytes_per_frame": bpf},
+                     "kernel_ms": kms, "bytes_per_frame": bpf, "valu_issue": valu},
     }
 
     # ---- reference semantics (early exit) at a.snr and +2 dB ---------------------------------------------

@@ -612,3 +612,17 @@ def test_odd_sizes_and_iteration_limits(A, oracle, matrices, pcm):
     ob, ook, oit = oracle.qpadmm_decode(Hb, yy, 0.0, 1.95, 0.5, 1, 1e-5)
     bits, ok, iters = A.QPADMMDecoder(1.95, 0.5, 1, 1e-5).decode_batch(H5, yy, 0.0)
     assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+
+
+def test_qpadmm_mc_block_and_wave_kernels_agree(A, pcm):
+    """QP-ADMM Monte-Carlo: the workgroup-per-frame kernel (auto) and the wavefront kernels (L = 64, 32) see the same
+    Philox frames and must return identical counters (decode is bit-exact in both)."""
+    H = pcm["H05"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 100, 3)
+    res = []
+    for lpf in (0, 64, 32):
+        dec = A.QPADMMDecoder(1.95, 0.5, 100, 1e-5, lanes_per_frame=lpf)
+        res.append(A.run_experiment(dec, cws, H, -1.0, frames=6000, first_frame=11, noise="device", seed=21).as_vector())
+        dec.close()
+    assert (res[0] == res[1]).all() and (res[0] == res[2]).all(), res
