@@ -984,8 +984,18 @@ int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t 
         for (int f = 0; f < frames; f++) {
             for (int e = 0; e < E; e++) {  // edge order: check-major, variables ascending (same as the oracle's trace)
                 c2v[(size_t) f * E + e] = get(hc, (size_t) e * 64 + f);
-                const double w = get(hv, (size_t) e * 64 + f);
-                v2c_mag[(size_t) f * E + e] = std::fabs(w);  // the LSB carries the hard bit: < 1 ulp of the magnitude
+                // a v->c word = magnitude | hard-decision bit in the LSB | sign: strip the LSB before reading it
+                double w;
+                if (f64) {
+                    uint64_t u = reinterpret_cast<const uint64_t *>(hv.data())[(size_t) e * 64 + f] & ~1ull;
+                    std::memcpy(&w, &u, 8);
+                } else {
+                    uint32_t u = reinterpret_cast<const uint32_t *>(hv.data())[(size_t) e * 64 + f] & ~1u;
+                    float wf;
+                    std::memcpy(&wf, &u, 4);
+                    w = unscale * (double) wf;
+                }
+                v2c_mag[(size_t) f * E + e] = std::fabs(w);
                 v2c_sgn[(size_t) f * E + e] = std::signbit(w) ? -1.0 : 1.0;
             }
             for (int v = 0; v < n; v++) post[(size_t) f * n + v] = get(hp, (size_t) v * 64 + f);

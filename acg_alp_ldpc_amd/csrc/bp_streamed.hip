@@ -41,7 +41,7 @@ struct StreamPass {
             T s = 0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                mag[j] = B::from(B::to(x[j]) & ~SIGN);
+                mag[j] = B::from(B::to(x[j]) & ~SIGN & ~ONE);  // LSB = hard bit, not magnitude
                 pre[j] = s;
                 s += mag[j];
             }
@@ -56,7 +56,7 @@ struct StreamPass {
             int am = -1;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const T a = B::from(B::to(x[j]) & ~SIGN);
+                const T a = B::from(B::to(x[j]) & ~SIGN & ~ONE);
                 const bool lt1 = a < m1, lt2 = a < m2;
                 m2 = lt1 ? m1 : (lt2 ? a : m2);
                 am = lt1 ? j : am;
@@ -153,7 +153,7 @@ __device__ __forceinline__ typename FpBits<T>::U check_group(T *__restrict__ Mp,
                 T s = 0;
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
-                    mag[j] = B::from(B::to(x[g][j]) & ~B::SIGN);
+                    mag[j] = B::from(B::to(x[g][j]) & ~B::SIGN & ~(U) 1);  // LSB = hard bit, not magnitude
                     pre[j] = s;
                     s += mag[j];
                 }
@@ -168,7 +168,7 @@ __device__ __forceinline__ typename FpBits<T>::U check_group(T *__restrict__ Mp,
                 int am = -1;
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
-                    const T a = B::from(B::to(x[g][j]) & ~B::SIGN);
+                    const T a = B::from(B::to(x[g][j]) & ~B::SIGN & ~(U) 1);
                     const bool lt1 = a < m1, lt2 = a < m2;
                     m2 = lt1 ? m1 : (lt2 ? a : m2);
                     am = lt1 ? j : am;

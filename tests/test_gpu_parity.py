@@ -626,3 +626,34 @@ def test_qpadmm_mc_block_and_wave_kernels_agree(A, pcm):
         res.append(A.run_experiment(dec, cws, H, -1.0, frames=6000, first_frame=11, noise="device", seed=21).as_vector())
         dec.close()
     assert (res[0] == res[1]).all() and (res[0] == res[2]).all(), res
+
+
+def test_non_finite_and_extreme_symbols(A, oracle, matrices, pcm):
+    """the reference has no clipping — zero, huge, infinite and NaN channel symbols flow through phi as
+    IEEE says (phi(0) = inf, inf - inf = NaN, NaN <= 0 is false -> bit 0).  Same hard outputs on the device."""
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 8, 200)
+    y = oracle.transmit_frames(cws, 1.0, first_seed=60000)
+    rng = np.random.default_rng(9)
+    for f in range(200):
+        k = rng.integers(0, 6)
+        idx = rng.choice(H.n, size=k, replace=False)
+        kind = f % 5
+        if kind == 0:
+            y[f, idx] = 0.0
+        elif kind == 1:
+            y[f, idx] = 1e6 * np.sign(y[f, idx] + 1e-9)
+        elif kind == 2:
+            y[f, idx] = np.inf * np.sign(1 - 2.0 * cws[f, idx] + 0.0)
+        elif kind == 3:
+            y[f, idx] = np.nan
+        else:
+            y[f, idx] = -np.inf      # wrong-signed certainty on up to 5 positions
+    ob, ook, oit = oracle.bp_decode(Hm, y, 1.0, 50, threads=8)
+    for kw in (dict(), dict(lanes_per_frame=64), dict(engine=A.ENGINE_STREAMED), dict(precision=A.PREC_F64)):
+        dec = A.BeliefPropagationDecoder(50, **kw)
+        bits, ok, iters = dec.decode_batch(H, y, 1.0)
+        dec.close()
+        bad = np.nonzero((ok != ook) | (bits != ob).any(axis=1) | (iters != oit))[0]
+        assert len(bad) == 0, (kw, bad[:10], [(int(f) % 5) for f in bad[:10]])
