@@ -657,3 +657,43 @@ def test_non_finite_and_extreme_symbols(A, oracle, matrices, pcm):
         dec.close()
         bad = np.nonzero((ok != ook) | (bits != ob).any(axis=1) | (iters != oit))[0]
         assert len(bad) == 0, (kw, bad[:10], [(int(f) % 5) for f in bad[:10]])
+
+
+def test_edge_graphs_and_extreme_symbols_other_engines(A, oracle, matrices, pcm):
+    """the ragged graph of test_bp_edge_cases (degree-1 / degree-2 checks, empty row, isolated variables) through the
+    streamed and workgroup-per-frame engines and min-sum; QP-ADMM with non-finite symbols"""
+    H = np.zeros((5, 9), np.uint8)
+    H[0, [0, 1, 2, 3]] = 1
+    H[1, [2, 3, 4]] = 1
+    H[2, [5]] = 1
+    H[3, [0, 6]] = 1
+    rng = np.random.default_rng(3)
+    y = 1.0 + 0.9 * rng.standard_normal((200, 9))
+    y[::7, 2] = 0.0
+    y[::11, 4] = np.inf
+    ob, ook, oit = oracle.bp_decode(H, y, 0.0, 12, threads=2)
+    mb, mok, mit = oracle.minsum_decode(H, y, 0.0, 12, 1.0, threads=2)
+    for kw in (dict(engine=A.ENGINE_STREAMED), dict(lanes_per_frame=256), dict(lanes_per_frame=16)):
+        dec = A.BeliefPropagationDecoder(12, **kw)
+        bits, ok, iters = dec.decode_batch(H, y, 0.0)
+        dec.close()
+        assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), kw
+        ms = A.MinSumDecoder(12, 1.0, precision=A.PREC_F64, **kw)
+        bits, ok, iters = ms.decode_batch(H, y, 0.0)
+        ms.close()
+        assert (ok == mok).all() and (bits == mb).all() and (iters == mit).all(), kw
+    Hm, H5 = matrices["H05"], pcm["H05"]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 8, 60)
+    yy = oracle.transmit_frames(cws, 0.0, first_seed=70000)
+    yy[0, 3] = np.nan
+    yy[1, 10] = np.inf
+    yy[2, 17] = -np.inf
+    yy[3, :5] = 0.0
+    yy[4, 100] = 1e300
+    ob, ook, oit = oracle.qpadmm_decode(Hm, yy, 0.0, 1.95, 0.5, 40, 1e-5, threads=4)
+    for lpf in (0, 64):
+        dec = A.QPADMMDecoder(1.95, 0.5, 40, 1e-5, lanes_per_frame=lpf)
+        bits, ok, iters = dec.decode_batch(H5, yy, 0.0)
+        dec.close()
+        assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), lpf
