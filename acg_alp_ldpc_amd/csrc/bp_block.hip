@@ -28,8 +28,12 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
     uint32_t *OB = reinterpret_cast<uint32_t *>(A + t.a_words);
     Core core(t, A, A, OB, IDX, l, a.ms_scale);
     typename Core::LlrRegs lr;
+    typename Core::VarIds vi;
 #pragma unroll
-    for (int p = 0; p < NVP; ++p) lr[p] = (T) 0;
+    for (int p = 0; p < NVP; ++p) {
+        lr[p] = (T) 0;
+        vi[p] = (p < t.n_vpass) ? t.v_var[p * L + l] : -1;
+    }
     unsigned long long acc_correct = 0, acc_pseudo = 0, acc_total = 0, acc_ham = 0, acc_ham_ok = 0, acc_ham_wrong = 0, acc_iters = 0;
     // padding words and the zero cell are +0.0 for the whole launch
     for (int w = l; w < t.a_words; w += L) A[w] = (T) 0;
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
         int my_ham = 0;
         for (int p = 0; p < t.n_vpass; ++p) {
             const int slot = p * L + l;
-            const int v = t.v_var[slot];
+            const int v = core.var_id(vi, p);
             T llr = (T) 0;
             if (v >= 0) {
                 if (MC) {
@@ -104,7 +108,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
             const bool finish = (a.early_exit && conv) || it >= a.max_iter;
             const bool fail_now = finish && !conv && !latched;
             if (out_now || fail_now) {  // block-uniform
-                if (out_now) core.pack_bits(lr);
+                if (out_now) core.pack_bits(lr, vi);
                 else {
                     for (int w = l; w < t.nwords; w += L) OB[w] = 0u;  // bp.h:198
                     __syncthreads();
