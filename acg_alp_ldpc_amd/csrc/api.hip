@@ -297,10 +297,8 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     }
     if (L == 0) {
         // Auto: a pass costs its largest degree for all L lanes, so finer groups waste fewer padded
-        // message slots (H05: 79% useful at L=64, 94% at L=32); two frames then share a wavefront and an
-        // early-exiting frame waits for its partner's restart.  Measured on MI355X (H05, 50 it, LLRs in
-        // registers): fixed work 15.5 M frames/s at L=32 vs 13.2 M at L=64; early exit 43.1 M vs 42.6 M at
-        // -2 dB and 227 M vs 206 M at +2 dB.
+        // message slots (H05: 79% useful at L=64, 94% at L=32).  Measured on MI355X (H05, 50 it): fixed work
+        // 19.0 M frames/s at L=32 vs 17.2 M at L=64; early exit 68.6 M vs 65.3 M at -2 dB, 296 M vs 285 M at +2 dB.
         BpLayout l64, l32;
         if (!bp_layout_build(c, 64, l64) || !bp_layout_build(c, 32, l32)) return 3;
         auto slots = [](const BpLayout &y) {
@@ -310,7 +308,7 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
             return (double) s;
         };
         const double gain = slots(l64) / std::max(1.0, slots(l32));
-        L = (gain > (d->p.early_exit ? 1.10 : 1.05)) ? 32 : 64;
+        L = (gain > 1.05) ? 32 : 64;
     }
     d->L = L;
     if (!bp_layout_build(c, L, d->lay)) return 3;
