@@ -125,3 +125,20 @@ def test_optimize_h_driver_runs_and_only_accepts_improvements(drivers, oracle, t
         cw2 = oracle.gen_codewords(Gn, 239, 300)
         res = oracle.experiment("qpadmm", Hn, cw2, -3.0, 200, 1.95, 0.5, 1e-5)
         assert (res["total"] - res["correct"]) / res["total"] == pytest.approx(cur, abs=1e-5)
+
+
+@pytest.mark.gpu
+def test_eval_driver_multi_handle_sharding(drivers, tmp_path):
+    """--gpus 3 (three handles + three host threads, folded onto the one device of the test box): contiguous global
+    frame ranges + merged counters give the same report as one handle, for host and for device noise"""
+    rows = {}
+    for tag, extra in (("one", []), ("three", ["--gpus", "3", "--device-count", "1"])):
+        for noise in ("host", "device"):
+            out = str(tmp_path / ("r_%s_%s.csv" % (tag, noise)))
+            r = subprocess.run([os.path.join(drivers, "acg_eval"), "--H", os.path.join(DATA, "H05.txt"), "--snrs", "-2",
+                                "--tests", "3001", "--bp-iters", "50", "--alpha", "1.95", "--mu", "0.5", "--admm-iters",
+                                "100", "--noise", noise, "--out", out] + extra, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr
+            rows[(tag, noise)] = [[x.split(",")[i] for i in (0, 1, 2, 3, 5, 6, 7)] for x in open(out).read().strip().splitlines()[1:]]
+    for noise in ("host", "device"):
+        assert rows[("one", noise)] == rows[("three", noise)]   # every column except Time

@@ -3,6 +3,7 @@
 //
 //   acg_eval --H data/optimalH.txt [--G data/G05.txt] [--snrs -5,-4.5,...,0] [--tests 10000] [--bp-iters 100]
 //            [--alpha 1.2 --mu 0.55 --admm-iters 10000 --eps 1e-5] [--noise host|device] [--seed 1] [--out report.csv]
+//            [--gpus N]   (one decoder handle + host thread per GPU, contiguous frame ranges, counters summed)
 // Defaults are main.cpp's (OPTIMAL build): optimalH, BP(100), QP-ADMM(1.2, 0.55, 10000, 1e-5), 10000 codewords from
 // mt19937(239'239'239), SNRs -5..0 step 0.5.  --noise host reproduces the reference's frames bit for bit
 // (frame i <- mt19937(i+1)); --noise device keeps generation, decoding and classification on the GPU.
@@ -31,19 +32,16 @@ int main(int argc, char **argv) {
     }
     std::cerr << "n=" << n << " k=" << m << "\n";  // main.cpp:66 (prints H.size() as k)
 
-    struct Dec {
-        std::string name;
-        acg_ldpc_decoder *h;
-    };
-    std::vector<Dec> decs;
+    const int gpus = (int) a.integer("--gpus", 1);
+    const int ndev = (int) a.integer("--device-count", 1 << 30);  // tests: fold N handles onto fewer devices
+    std::vector<drv::MultiGpu> decs;
     acg_ldpc_params p;
     if (!a.has("--no-bp")) {
         acg_ldpc_params_default(&p);
         p.algo = ACG_LDPC_BP_SUMPRODUCT;
         p.max_iter = (int) a.integer("--bp-iters", 100);  // main.cpp:29
-        acg_ldpc_decoder *d = nullptr;
-        if (acg_ldpc_decoder_create(code, &p, &d)) drv::die("create BP");
-        decs.push_back({acg_ldpc_decoder_name(d), d});
+        decs.emplace_back();
+        decs.back().create(code, p, gpus, ndev);
     }
     if (!a.has("--no-admm")) {
         acg_ldpc_params_default(&p);
@@ -52,9 +50,8 @@ int main(int argc, char **argv) {
         p.mu = a.num("--mu", 0.55);
         p.max_iter = (int) a.integer("--admm-iters", 10000);
         p.eps_stop = a.num("--eps", 1e-5);
-        acg_ldpc_decoder *d = nullptr;
-        if (acg_ldpc_decoder_create(code, &p, &d)) drv::die("create QP-ADMM");
-        decs.push_back({acg_ldpc_decoder_name(d), d});
+        decs.emplace_back();
+        decs.back().create(code, p, gpus, ndev);
     }
 
     std::cout.precision(5);
@@ -64,18 +61,18 @@ int main(int argc, char **argv) {
     fdata << std::fixed << std::setprecision(12);
     for (double snr : snrs) std::cerr << "snr=" << snr << ": var=" << acg_ldpc_llr_variance(snr) << std::endl;
     for (auto &d : decs) {
-        std::cout << "Algo: " << d.name << std::endl;
+        std::cout << "Algo: " << d.name() << std::endl;
         for (double snr : snrs) {
-            drv::McOut r = drv::run_mc(d.h, cws, n, snr, tests, noise, (uint64_t) a.integer("--seed", 1));
+            drv::McOut r = d.run(cws, n, snr, tests, noise, (uint64_t) a.integer("--seed", 1));
             std::cout << "\tSNR: " << snr << ", FER: " << r.fer() << ", (time=" << r.avg_time() << "s)" << std::endl;
             std::cerr << "\t\tAverage hamming distance: " << r.mean_hamming() << std::endl;
-            fdata << d.name << "," << snr << "," << std::sqrt(acg_ldpc_llr_variance(snr)) << "," << r.fer() << ","
+            fdata << d.name() << "," << snr << "," << std::sqrt(acg_ldpc_llr_variance(snr)) << "," << r.fer() << ","
                   << r.avg_time() << "," << r.mean_hamming() << "," << r.mean_hamming_ok() << ","
                   << r.mean_hamming_wrong() << std::endl;
         }
         std::cerr << std::string(30, '_') << std::endl;
     }
-    for (auto &d : decs) acg_ldpc_decoder_destroy(d.h);
+    for (auto &d : decs) d.destroy();
     acg_ldpc_code_destroy(code);
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "acg_ldpc.h"
@@ -116,5 +117,62 @@ inline std::vector<uint8_t> make_codewords(const acg_ldpc_code *code, const char
     if (acg_ldpc_gen_codewords(G.data(), k, n, seed, count, cw.data())) die("gen_codewords");
     return cw;
 }
+
+// One decoder handle per GPU; a Monte-Carlo run is cut into contiguous global frame ranges, one per handle, run from
+// one host thread per device and merged with acg_ldpc_mc_merge (experiment.h:70-78) — frames are independent, so
+// nothing but seven counters crosses devices.  Device k of `gpus` maps to ordinal k % device_count, so
+// the sharding logic can be exercised on a one-GPU box.
+struct MultiGpu {
+    std::vector<acg_ldpc_decoder *> dec;
+
+    void create(const acg_ldpc_code *code, acg_ldpc_params p, int gpus, int device_count) {
+        for (int k = 0; k < gpus; k++) {
+            p.device = device_count > 0 ? k % device_count : -1;
+            acg_ldpc_decoder *d = nullptr;
+            if (acg_ldpc_decoder_create(code, &p, &d)) die("acg_ldpc_decoder_create");
+            dec.push_back(d);
+        }
+    }
+    void destroy() {
+        for (auto *d : dec) acg_ldpc_decoder_destroy(d);
+        dec.clear();
+    }
+    const char *name() const { return acg_ldpc_decoder_name(dec[0]); }
+
+    McOut run(const std::vector<uint8_t> &codewords, int n, double snr, int64_t frames, int noise, uint64_t seed) const {
+        const int W = (int) dec.size();
+        std::vector<McOut> part((size_t) W);
+        std::vector<std::string> err((size_t) W);
+        std::vector<std::thread> th;
+        for (int r = 0; r < W; r++)
+            th.emplace_back([&, r] {
+                const int64_t lo = frames * r / W, hi = frames * (r + 1) / W;
+                acg_ldpc_mc_cfg cfg;
+                std::memset(&cfg, 0, sizeof cfg);
+                cfg.frames = hi - lo;
+                cfg.first_frame = lo;  // seeds derive from the GLOBAL frame index: same frames for any W
+                cfg.snr = snr;
+                cfg.seed = seed;
+                cfg.noise = noise;
+                cfg.codewords = codewords.empty() ? nullptr : codewords.data();
+                cfg.n_codewords = codewords.empty() ? 0 : (int64_t) (codewords.size() / (size_t) n);
+                if (acg_ldpc_mc_run(dec[(size_t) r], &cfg, &part[(size_t) r].r)) err[(size_t) r] = acg_ldpc_last_error();
+            });
+        for (auto &t : th) t.join();
+        McOut tot;
+        std::memset(&tot.r, 0, sizeof tot.r);
+        double wall = 0;
+        for (int r = 0; r < W; r++) {
+            if (!err[(size_t) r].empty()) {
+                std::fprintf(stderr, "acg_ldpc_mc_run (shard %d): %s\n", r, err[(size_t) r].c_str());
+                std::exit(1);
+            }
+            wall = wall > part[(size_t) r].r.time_sec ? wall : part[(size_t) r].r.time_sec;
+            acg_ldpc_mc_merge(&tot.r, &part[(size_t) r].r);
+        }
+        tot.r.time_sec = wall;  // shards run concurrently: the slowest one is the wall time
+        return tot;
+    }
+};
 
 }  // namespace drv
