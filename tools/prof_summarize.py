@@ -19,7 +19,7 @@ def find(pat):
 summary = {"bench_args": args}
 stats = find("prof_stats/**/*kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
-main = [r for r in rows if "_fused_kernel" in r["Name"] or "_streamed_kernel" in r["Name"]]
+main = [r for r in rows if any(k in r["Name"] for k in ("_fused_kernel", "_streamed_kernel", "_block_kernel"))]
 summary["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                             "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
                             "pct": float(r["Percentage"])} for r in rows[:6]]
