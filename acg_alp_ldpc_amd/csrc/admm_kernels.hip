@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
                         const int v = 4 * q + e;
                         if (v < t.n) {
                             const uint32_t bit = cw ? ((cw[v >> 5] >> (v & 31)) & 1u) : 0u;
-                            V[v] = (T) ((bit ? -1.0f : 1.0f) + a.sigma * z[e]);
+                            V[v] = (T) __builtin_fmaf(a.sigma, z[e], bit ? -1.0f : 1.0f);  // explicit fma: same symbol in every TU (this one is built with -ffp-contract=off)
                         }
                     }
                 }
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(ADMM_BLK) admm_block_kernel(const AdmmDevTable
                     const int v = 4 * q + e;
                     if (v < t.n) {
                         const uint32_t bit = cw ? ((cw[v >> 5] >> (v & 31)) & 1u) : 0u;
-                        V[v] = (T) ((bit ? -1.0f : 1.0f) + a.sigma * z[e]);
+                        V[v] = (T) __builtin_fmaf(a.sigma, z[e], bit ? -1.0f : 1.0f);  // explicit fma: same symbol in every TU (this one is built with -ffp-contract=off)
                     }
                 }
             }
@@ -898,6 +898,13 @@ void admm_device_destroy(AdmmDevice *d) {
     if (!d) return;
     for (void *p : d->allocs) (void) hipFree(p);
     delete d;
+}
+
+// true when Monte-Carlo runs should go AWGN kernel -> decode -> classify kernel instead of the fused MC kernel
+bool admm_device_unfused_mc(const AdmmDevice *d, const int32_t **row_ptr, const int32_t **edge_var) {
+    if (row_ptr) *row_ptr = d->t.row_ptr;
+    if (edge_var) *edge_var = d->t.edge_var;
+    return d->blockmode && !d->guard;
 }
 
 void admm_device_layout(const AdmmDevice *d, int *lds_per_frame, int *lanes, int *frames_per_block, int *grid) {

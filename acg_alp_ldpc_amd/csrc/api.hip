@@ -35,13 +35,15 @@ hipError_t bp_streamed_launch(const void *kernel, const StreamTables &t, const D
                               int block, hipStream_t s);
 hipError_t classify_launch(const float *y, const uint32_t *bits, const uint8_t *ok, const int32_t *iters, int64_t frames,
                            int n, int nwords, int64_t first_frame, const uint32_t *cw_packed, int64_t n_cw,
-                           unsigned long long *counters, hipStream_t s);
+                           unsigned long long *counters, const int32_t *row_ptr, const int32_t *edge_var, int m,
+                           hipStream_t s);
 
 struct AdmmDevice;  // admm_kernels.hip
 AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_count, std::string &err);
 void admm_device_destroy(AdmmDevice *d);
 hipError_t admm_launch(AdmmDevice *d, const DecodeArgs &a, hipStream_t s, std::string &err);
 void admm_device_layout(const AdmmDevice *d, int *lds_per_frame, int *lanes, int *frames_per_block, int *grid);
+bool admm_device_unfused_mc(const AdmmDevice *d, const int32_t **row_ptr, const int32_t **edge_var);
 
 #define HIP_OK(expr)                                                                            \
     do {                                                                                        \
@@ -799,8 +801,12 @@ int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc
     int rc = 0;
     if (cfg->noise == ACG_LDPC_NOISE_HOST_MT19937) {
         rc = mc_run_host_noise(d, cfg, res);
-    } else if (d->streamed) {
-        // no in-kernel generator: AWGN kernel -> decode -> classify kernel, in bounded chunks, all on the device
+    } else if (d->streamed || (d->admm && admm_device_unfused_mc(d->admm, nullptr, nullptr))) {
+        // AWGN kernel -> decode -> classify kernel, in bounded chunks, all on the device.  Used by the streamed BP
+        // engine (no in-kernel generator) and by the workgroup-per-frame QP-ADMM kernel, whose fused Monte-Carlo
+        // variant needs 156 VGPRs (3 waves/SIMD) against 117 (4) for the plain decode: 1.6 M vs 2.7 M frames/s.
+        const int32_t *csr_row = nullptr, *csr_col = nullptr;
+        if (d->admm) (void) admm_device_unfused_mc(d->admm, &csr_row, &csr_col);
         std::lock_guard<std::mutex> lk(d->mu);
         HIP_OK(hipSetDevice(d->device));
         if ((rc = ensure_codewords(d, cfg))) return rc;
@@ -831,7 +837,7 @@ int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc
             if ((rc = launch_decode(d, a, d->stream))) return rc;
             HIP_OK(classify_launch(d->mc_y, d->st_bits, d->st_ok, d->st_iters, fc, n, nwords, cfg->first_frame + f0,
                                    cfg->codewords ? d->cw_dev : nullptr, cfg->codewords ? cfg->n_codewords : 1,
-                                   d->counters, d->stream));
+                                   d->counters, csr_row, csr_col, d->c.m, d->stream));
             HIP_OK(hipStreamSynchronize(d->stream));
             float ms = 0;
             if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) kms += ms;

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                     const int v = 4 * q + e;
                     if (v < t.n) {
                         const uint32_t bit = cw ? ((cw[v >> 5] >> (v & 31)) & 1u) : 0u;
-                        A[v] = (T) ((bit ? -1.0f : 1.0f) + a.sigma * z[e]);  // channel.h:24
+                        A[v] = (T) __builtin_fmaf(a.sigma, z[e], bit ? -1.0f : 1.0f);  // channel.h:24 (explicit fma: same symbol in every kernel)
                     }
                 }
             }

@@ -97,7 +97,7 @@ __global__ void awgn_kernel(float *y, int64_t frames, int n, int nwords, int64_t
             const int v = 4 * q + e;
             if (v < n) {
                 const uint32_t bit = cw ? ((cw[v >> 5] >> (v & 31)) & 1u) : 0u;
-                y[(size_t) f * n + v] = (bit ? -1.0f : 1.0f) + sigma * z[e];
+                y[(size_t) f * n + v] = __builtin_fmaf(sigma, z[e], bit ? -1.0f : 1.0f);  // explicit fma: same symbol in every kernel
             }
         }
     }
@@ -107,7 +107,8 @@ __global__ void awgn_kernel(float *y, int64_t frames, int n, int nwords, int64_t
 // one wavefront per frame; correct <=> ok and bits == sent word; raw-channel Hamming count from y.
 __global__ void classify_kernel(const float *y, const uint32_t *bits, const uint8_t *ok, const int32_t *iters,
                                 int64_t frames, int n, int nwords, int64_t first_frame, const uint32_t *cw_packed,
-                                int64_t n_cw, unsigned long long *counters) {
+                                int64_t n_cw, unsigned long long *counters, const int32_t *row_ptr,
+                                const int32_t *edge_var, int m) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nw = (int64_t) gridDim.x * (blockDim.x >> 6);
@@ -125,7 +126,19 @@ __global__ void classify_kernel(const float *y, const uint32_t *bits, const uint
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ham += __shfl_xor(ham, o, 64);
         const bool differ = __ballot(neq) != 0ull;
-        const bool okf = ok[f] != 0;
+        bool okf = ok[f] != 0;
+        if (row_ptr) {  // decoders that always report ok (QP-ADMM, qp_admm.h:177): IsCodeword here (experiment.h:111)
+            bool sbad = false;
+            for (int c = lane; c < m; c += 64) {
+                uint32_t sy = 0;
+                for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e) {
+                    const int v = edge_var[e];
+                    sy ^= (bits[(size_t) f * nwords + (v >> 5)] >> (v & 31)) & 1u;
+                }
+                sbad |= (sy != 0u);
+            }
+            okf = okf && (__ballot(sbad) == 0ull);
+        }
         const bool correct = okf && !differ;
         c_ok += correct;
         c_ps += (okf && differ);
@@ -148,11 +161,12 @@ __global__ void classify_kernel(const float *y, const uint32_t *bits, const uint
 
 hipError_t classify_launch(const float *y, const uint32_t *bits, const uint8_t *ok, const int32_t *iters, int64_t frames,
                            int n, int nwords, int64_t first_frame, const uint32_t *cw_packed, int64_t n_cw,
-                           unsigned long long *counters, hipStream_t s) {
+                           unsigned long long *counters, const int32_t *row_ptr, const int32_t *edge_var, int m,
+                           hipStream_t s) {
     int grid = (int) std::min<int64_t>((frames + 3) / 4, 256 * 8);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, y, bits, ok, iters, frames, n, nwords, first_frame,
-                       cw_packed, n_cw, counters);
+                       cw_packed, n_cw, counters, row_ptr, edge_var, m);
     return hipGetLastError();
 }
 
