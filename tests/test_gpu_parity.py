@@ -697,3 +697,36 @@ def test_edge_graphs_and_extreme_symbols_other_engines(A, oracle, matrices, pcm)
         bits, ok, iters = dec.decode_batch(H5, yy, 0.0)
         dec.close()
         assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), lpf
+
+
+# ---------------------------------------------------------------------------------------- the reference's published tables
+@pytest.mark.parametrize("matrix,gfile,alpha,mu,rows", [
+    # reports/report_H05.csv:17,19,21 (QP-ADMM rows) and :6,8 (BP rows below the race floor)
+    ("H05", "G05.txt", 1.95, 0.5, {"qpadmm": {-3.0: 0.3380, -2.0: 0.0379, -1.0: 0.0016}, "bp": {-3.0: 0.5185, -2.0: 0.1038}}),
+    # reports/report_opt.csv:17,19,21 and :6,8
+    ("optimalH", None, 1.2, 0.55, {"qpadmm": {-3.0: 0.2751, -2.0: 0.0245, -1.0: 0.0001}, "bp": {-3.0: 0.4860, -2.0: 0.0851}}),
+])
+def test_published_fer_tables_statistically(A, pcm, oracle, matrix, gfile, alpha, mu, rows):
+    """The only numbers the reference publishes for this path: FER per SNR over 10^4 frames with BP(100) and
+    QP-ADMM(alpha, mu, 10000, 1e-5) (main.cpp:25-33).  Same pipeline here (codewords mt19937(239'239'239), frame i
+    <- mt19937(i+1)); their run used 8 racy threads and another standard library, so the pin is
+    statistical: inside the 99.9 % binomial interval of two independent 10^4-frame estimates."""
+    from math import sqrt
+    H = pcm[matrix]
+    if gfile:
+        G = oracle.read_pcm(os.path.join(DATA, gfile))      # main.cpp:59-60 (non-OPTIMAL build)
+    else:
+        G, _ = H.get_orthogonal()                             # main.cpp:56-57
+    cws = A.gen_random_codewords(G, 10000, 239239239)
+    decs = {"bp": A.BeliefPropagationDecoder(100), "qpadmm": A.QPADMMDecoder(alpha, mu, 10000, 1e-5)}
+    for kind, tab in rows.items():
+        for snr, p_ref in tab.items():
+            r = A.run_experiment(decs[kind], cws, H, snr, noise="host")
+            half = 3.29 * sqrt(2 * max(p_ref, 3e-4) * (1 - p_ref) / 10000) + 2e-4
+            if kind == "bp" and snr > -2.5:
+                # the published BP rows carry the Node::counter race of the 8-thread run (SURVEY D5: floor 0.034 at
+                # >= -1 dB); it only ever ADDS failures, already ~ +0.017 at -2 dB (0.1038 published vs 0.0868 for the
+                # race-free decoder, which is bit-identical to the single-threaded reference on 10^5 frames)
+                assert p_ref - 0.03 < r.FER() < p_ref + half, (matrix, kind, snr, r.FER(), p_ref)
+            else:
+                assert abs(r.FER() - p_ref) < half, (matrix, kind, snr, r.FER(), p_ref, half)
