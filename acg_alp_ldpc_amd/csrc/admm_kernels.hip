@@ -89,6 +89,12 @@ struct AdmmDevTables {
     const int32_t *v_list_off;   // [n_vpass]
     const uint32_t *v_list;      // entries gslot | wpos << 20 | type << 22 ; padding -> zero slot, type 0
     const void *inv_coef;        // [n_vpass*L] T
+    // workgroup-per-frame kernel (admm_block_kernel): the same structure pre-digested into LDS byte addresses
+    const uint32_t *blk_mem;   // [3][G_pad] address of V[member k] | address of U[group][wpos k] << 16
+    const uint32_t *blk_list;  // laid out like v_list: address of U[group][0] | "coefficient -1" flags (row r at bit 31-r)
+    const int32_t *blk_mlw;    // [n_vpass][4] longest list among the variables of (pass, wavefront)
+    const uint8_t *grp_type_slot;  // [G_pad] group type per slot of the workgroup-per-frame kernel (type-3 groups first)
+    const uint8_t *blk_generic;    // [n_gpass][4] 1 = (pass, wavefront) holds one- or two-variable checks
     // syndrome (MC classification)
     const int32_t *row_ptr;
     const int32_t *edge_var;
@@ -438,183 +444,278 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Workgroup-per-frame variant: the 256 threads of a workgroup own ONE frame (requires <= 4*256 constraint groups
-// and variables).  Same arithmetic, same order of every rounding step as the wavefront variant; the LDS footprint
-// per frame is unchanged but four times as many wavefronts work on it, which is what this latency-bound sweep
-// needs (one wavefront per frame left 5 waves per CU: 1.25 per SIMD).  Row state w and the channel terms q live in
-// registers (4 passes at most), LDS holds u_j = yl_j + mu*(z_j - b_j) and v.
+// Workgroup-per-frame variant: the 128/192/256 threads of a workgroup own ONE frame (requires <= 4 passes of
+// constraint groups and variables).  Same arithmetic and the same order of every rounding step as the wavefront
+// variant, organised so that nothing loop-invariant is recomputed inside a sweep:
+//  * everything a thread needs about its groups and variables (LDS addresses, signs, list entries, channel term,
+//    1/coefficient) is loaded ONCE per kernel / frame into registers; a sweep touches no global memory;
+//  * U is stored [group][row], so the v-update fetches the four rows of a list entry with one 128-bit (fp32) or two
+//    (fp64) LDS reads and one address; the +-1 coefficient of a row is rebuilt from a flag bit of the entry
+//    (sign bit OR'ed onto the bit pattern of 1.0) and applied with an fma, which rounds like `B += cf * (...)`;
+//  * the row phase works in "member order": slot k of a group is the row in which member k (ascending variable id)
+//    has coefficient +1, i.e. row wpos[k] (qp_admm.h:48-70); the three residuals of those rows are
+//        (-v0 + v1) + v2,  (v0 - v1) + v2,  (v0 + v1) - v2
+//    — exactly what `r -= A_jk * v_k` in ascending variable order gives, with the common sub-expression v0 - v1
+//    shared (-(a - b) == b - a exactly) — and row 3 is ((2 - v0) - v1) - v2.  The row state w lives in registers in
+//    slot order; the result of slot k is stored to U[group][wpos[k]] through a precomputed address, so the v-update
+//    still reads rows in construction order;
+//  * yl + mu*(z - b) with b = 0 is max(mu*z, -w) (one of yl, z is zero, x + 0 is exact);
+//  * the residual sum is only computed when the stopping rule is on (template EE), reduced with DPP lane
+//    exchanges instead of LDS permutes.
 constexpr int ADMM_BLK = 256;
 constexpr int ADMM_BP = 4;
+constexpr int ADMM_VK = 6;  // list entries per variable slot kept in registers (longer lists continue from global)
 
-template <typename T, bool MC>
-__global__ void __launch_bounds__(ADMM_BLK) admm_block_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
+template <typename T> struct AdmmVec;
+template <> struct AdmmVec<double> {
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ double pm1(uint32_t x) {  // bit 31 of x set -> -1.0, else +1.0
+        return __hiloint2double((int) ((x & 0x80000000u) | 0x3FF00000u), 0);
+    }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
+};
+template <> struct AdmmVec<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float pm1(uint32_t x) { return __uint_as_float((x & 0x80000000u) | 0x3F800000u); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
+};
+
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v, const int ctrl_tag) {
+    // ctrl_tag: 0 quad_perm[1,0,3,2]  1 quad_perm[2,3,0,1]  2 row_half_mirror  3 row_mirror
+    switch (ctrl_tag) {
+        case 0: return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0xB1, 0xF, 0xF, true);
+        case 1: return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x4E, 0xF, 0xF, true);
+        case 2: return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x141, 0xF, 0xF, true);
+        default: return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x140, 0xF, 0xF, true);
+    }
+}
+
+// sum over the 64 lanes of a wavefront, identical in every lane (fixed order: butterfly inside rows of 16, then rows)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t lo = dpp_u32((uint32_t) __double2loint(v), s), hi = dpp_u32((uint32_t) __double2hiint(v), s);
+        v += __hiloint2double((int) hi, (int) lo);
+    }
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * k), __builtin_amdgcn_readlane(__double2loint(v), 16 * k));
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v += __uint_as_float(dpp_u32(__float_as_uint(v), s));
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(v), 16 * k));
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
+
+// One constraint group (slot order, see above).  GENERIC also handles one- and two-variable checks, whose missing
+// slots must stay all-zero; the host puts those groups into passes/wavefronts flagged for the GENERIC instance so the
+// common instance carries no selects.  State yl[] = max(0, yl - r) of the previous sweep (qp_admm.h:157).
+template <typename T, bool EE, bool GENERIC>
+__device__ __forceinline__ void admm_group_update(unsigned char *smem, const uint32_t lds0, const uint32_t m0, const uint32_t m1,
+                                                  const uint32_t m2, const uint32_t u3_addr, const uint32_t ty, const T mu,
+                                                  T (&yl)[4], T &sum2) {
+    using X = AdmmVec<T>;
+    const T v0 = *reinterpret_cast<const T *>(smem + ((m0 & 0xFFFFu) + lds0));
+    const T v1 = *reinterpret_cast<const T *>(smem + ((m1 & 0xFFFFu) + lds0));
+    const T v2 = *reinterpret_cast<const T *>(smem + ((m2 & 0xFFFFu) + lds0));
+    const T d01 = v0 - v1;
+    T r[4];
+    r[0] = v2 - d01;        // ((0 - v0) + v1) + v2
+    r[1] = d01 + v2;        // ((0 + v0) - v1) + v2
+    r[2] = (v0 + v1) - v2;  // ((0 + v0) + v1) - v2
+    r[3] = (((T) 2 - v0) - v1) - v2;
+    if (GENERIC && ty != 3u) {
+        if (ty < 2u) r[1] = (T) 0;
+        r[2] = (T) 0;
+        r[3] = (T) 0;
+    }
+    T u[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const T wn = r[s] - yl[s];
+        const T z = X::max(wn, (T) 0);
+        yl[s] = X::max(-wn, (T) 0);
+        if (s < 3) u[s] = X::max(mu * z, -wn);  // yl + mu*(z - 0): one of yl, z is zero and x + 0 is exact
+        else u[s] = yl[s] + mu * (z - (T) 2);
+        if (EE) {
+            const T dd = z - r[s];
+            sum2 += dd * dd;
+        }
+    }
+    if (GENERIC && ty != 3u) u[3] = (T) 0;
+    *reinterpret_cast<T *>(smem + ((m0 >> 16) + lds0)) = u[0];
+    *reinterpret_cast<T *>(smem + ((m1 >> 16) + lds0)) = u[1];
+    *reinterpret_cast<T *>(smem + ((m2 >> 16) + lds0)) = u[2];
+    *reinterpret_cast<T *>(smem + (u3_addr + lds0)) = u[3];
+}
+
+template <typename T, bool EE>
+__global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
                                                               const T mu, const T eps_stop) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using X = AdmmVec<T>;
+    typedef typename X::v4 T4;
+    extern __shared__ __attribute__((aligned(32))) unsigned char smem[];
     const int L = blockDim.x;  // 128, 192 or 256 threads = one frame
     __shared__ T red[4];
     __shared__ unsigned long long fr_lds;
-    __shared__ int flag_lds[2];
-    __shared__ int ham_lds;
-    const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
-    T *U = reinterpret_cast<T *>(smem);  // [4][G_pad]
-    T *V = U + 4 * t.G_pad;              // [V_pad] by variable id (+ zero cell at n_var)
-    uint32_t *OB = reinterpret_cast<uint32_t *>(V + t.V_pad);
+    const int l = threadIdx.x, lane = l & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(l >> 6);
+    // LDS: V[V_pad] by variable id (+ zero cell at n_var) | U[G_pad][4] | packed hard decisions
+    T *V = reinterpret_cast<T *>(smem);
+    const uint32_t u_base = (uint32_t) t.V_pad * (uint32_t) sizeof(T);
+    uint32_t *OB = reinterpret_cast<uint32_t *>(smem + u_base + (size_t) 4 * t.G_pad * sizeof(T));
+    // ---- loop-invariant per-thread structure -> registers ------------------------------------------------------------
+    uint32_t mem[ADMM_BP][3];  // member k of my group in pass p: LDS byte address of V[member] | address of U[group][wpos k] << 16
+    uint32_t tys = 0;          // group type of pass p at bits 2p..2p+1 (0 = padding slot)
+#pragma unroll
+    for (int p = 0; p < ADMM_BP; ++p) {
+        mem[p][0] = mem[p][1] = mem[p][2] = 0;
+        if (p < t.n_gpass) {
+            const int gs = p * L + l;
+            tys |= (uint32_t) t.grp_type_slot[gs] << (2 * p);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) mem[p][k] = t.blk_mem[(size_t) k * t.G_pad + gs];
+        }
+    }
+    uint32_t ent[ADMM_BP][ADMM_VK];  // list entries: LDS byte address of U[group][0] | "coefficient is -1" flags, row r at bit 31-r
+    uint32_t mlw_pk = 0;             // list length of (pass p, my wavefront) at bits 8p..8p+7
+    uint32_t gen_pk = 0;             // bit p: (pass p, my wavefront) holds one- or two-variable checks
+    int vaddr[ADMM_BP];              // LDS byte address of my variable in pass p, -1 = none
+    T inv[ADMM_BP];
     const T *inv_coef = reinterpret_cast<const T *>(t.inv_coef);
-    unsigned long long acc_correct = 0, acc_pseudo = 0, acc_total = 0, acc_ham = 0, acc_ham_ok = 0, acc_ham_wrong = 0, acc_iters = 0;
-    T wreg[ADMM_BP][4], qreg[ADMM_BP];
+#pragma unroll
+    for (int p = 0; p < ADMM_BP; ++p) {
+        vaddr[p] = -1;
+        inv[p] = (T) 0;
+#pragma unroll
+        for (int k = 0; k < ADMM_VK; ++k) ent[p][k] = 0;
+        if (p < t.n_gpass) gen_pk |= (uint32_t) (t.blk_generic[p * 4 + wave] != 0) << p;
+        if (p < t.n_vpass) {
+            const int ml = t.blk_mlw[p * 4 + wave];
+            mlw_pk |= (uint32_t) ml << (8 * p);
+            const int i = t.var_of_slot[p * L + l];
+            vaddr[p] = (i >= 0) ? i * (int) sizeof(T) : -1;
+            inv[p] = inv_coef[p * L + l];
+#pragma unroll
+            for (int k = 0; k < ADMM_VK; ++k)
+                if (k < ml) ent[p][k] = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
+        }
+    }
+    mlw_pk = (uint32_t) __builtin_amdgcn_readfirstlane((int) mlw_pk);
+    gen_pk = (uint32_t) __builtin_amdgcn_readfirstlane((int) gen_pk);
+    T ylreg[ADMM_BP][4], qreg[ADMM_BP];
 
     for (;;) {
         __syncthreads();
-        if (l == 0) {
-            fr_lds = atomicAdd(a.work_counter, 1ull);  // dynamic frame hand-out
-            ham_lds = 0;
-            flag_lds[0] = 0;
-            flag_lds[1] = 0;
-        }
+        if (l == 0) fr_lds = atomicAdd(a.work_counter, 1ull);  // dynamic frame hand-out
         __syncthreads();
         const int64_t frame = (int64_t) fr_lds;
         if (frame >= a.frames) break;
-        const int64_t gf = a.first_frame + frame;
-        const uint32_t *cw = (MC && a.cw_packed) ? a.cw_packed + (size_t) (gf % a.n_cw) * t.nwords : nullptr;
         // ---- start of a frame --------------------------------------------------------------------------------
-        if (MC) {
-            const int nq = (t.n + 3) >> 2;
-            for (int q = l; q < nq; q += L) {
-                uint32_t r[4];
-                philox((uint32_t) gf, (uint32_t) (gf >> 32), (uint32_t) q, 0u, (uint32_t) a.seed, (uint32_t) (a.seed >> 32), r);
-                float z[4];
-                box_muller(r[0], r[1], z[0], z[1]);
-                box_muller(r[2], r[3], z[2], z[3]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int v = 4 * q + e;
-                    if (v < t.n) {
-                        const uint32_t bit = cw ? ((cw[v >> 5] >> (v & 31)) & 1u) : 0u;
-                        V[v] = (T) __builtin_fmaf(a.sigma, z[e], bit ? -1.0f : 1.0f);  // explicit fma: same symbol in every TU (this one is built with -ffp-contract=off)
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        int my_ham = 0;
 #pragma unroll
         for (int p = 0; p < ADMM_BP; ++p) {
-            qreg[p] = (T) 0;
+            T q = (T) 0;  // auxiliaries: q = 0 (qp_admm.h:24)
             if (p < t.n_vpass) {
-                const int i = t.var_of_slot[p * L + l];
-                T q = (T) 0;  // auxiliaries: q = 0 (qp_admm.h:24)
-                if (i >= 0 && i < t.n) {
-                    if (MC) {
-                        const T yv = V[i];
-                        const uint32_t bit = cw ? ((cw[i >> 5] >> (i & 31)) & 1u) : 0u;
-                        my_ham += ((!bit && yv <= (T) 0) || (bit && yv > (T) 0)) ? 1 : 0;
-                        q = (T) (2 * (double) yv / a.var);
-                    } else if (a.y_is_f64) {
-                        q = (T) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + i] / a.var);
-                    } else {
-                        q = (T) (2 * (double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + i] / a.var);
-                    }
+                const int i = vaddr[p] / (int) sizeof(T);
+                if (vaddr[p] >= 0 && i < t.n) {
+                    if (a.y_is_f64) q = (T) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + i] / a.var);
+                    else q = (T) (2 * (double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + i] / a.var);
                 }
-                qreg[p] = q;  // CalculateCoef, algo/algo.h:13-20
             }
+            qreg[p] = q;  // CalculateCoef, algo/algo.h:13-20
         }
-        if (MC) {
-            my_ham = group_sum<64, int>(my_ham);
-            if (lane == 0) atomicAdd(&ham_lds, my_ham);
-        }
-        __syncthreads();  // staged symbols consumed
         for (int w = l; w < t.V_pad; w += L) V[w] = (T) 0;
 #pragma unroll
-        for (int p = 0; p < ADMM_BP; ++p)
+        for (int p = 0; p < ADMM_BP; ++p) {
+#pragma unroll
+            for (int row = 0; row < 4; ++row) ylreg[p][row] = (T) 0;  // z = yl = 0 (qp_admm.h:120-121)
             if (p < t.n_gpass) {
                 const int gs = p * L + l;
-                const int ty = t.grp_type[gs];
-#pragma unroll
-                for (int row = 0; row < 4; ++row) {
-                    wreg[p][row] = (T) 0;  // z = yl = 0 (qp_admm.h:120-121)
-                    const T b = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
-                    U[row * t.G_pad + gs] = (T) 0 + mu * ((T) 0 - b);
-                }
+                T4 u0;
+                u0.x = u0.y = u0.z = (T) 0 + mu * ((T) 0 - (T) 0);
+                u0.w = (((tys >> (2 * p)) & 3u) == 3u) ? (T) 0 + mu * ((T) 0 - (T) 2) : (T) 0 + mu * ((T) 0 - (T) 0);
+                *reinterpret_cast<T4 *>(smem + u_base + (size_t) gs * sizeof(T4)) = u0;
             }
+        }
         __syncthreads();
         // ---- sweeps (qp_admm.h:130-164) ------------------------------------------------------------------------
         int it = 0;
         while (it < a.max_iter) {
+            // Constants the compiler must not see through: everything derived from the register-resident tables
+            // (addresses, +-1 patterns) would otherwise be hoisted out of the sweep loop into ~5 registers per entry.
+            uint32_t k80, k1, k2, k3, lds0, one_hi, mlw_o = mlw_pk, gen_o = gen_pk;
+            asm volatile("s_mov_b32 %0, 0x80000000\n\ts_mov_b32 %1, 1\n\ts_mov_b32 %2, 2\n\ts_mov_b32 %3, 3\n\ts_mov_b32 %4, 0"
+                         : "=s"(k80), "=s"(k1), "=s"(k2), "=s"(k3), "=s"(lds0));
+            if (sizeof(T) == 8) asm volatile("v_mov_b32 %0, 0x3ff00000" : "=v"(one_hi));  // in a VGPR: (x & k80) | one_hi is one v_and_or_b32
+            else asm volatile("v_mov_b32 %0, 1.0" : "=v"(one_hi));
+            asm volatile("" : "+s"(mlw_o), "+s"(gen_o));
+            auto pm1 = [&](uint32_t x) -> T {  // bit 31 of x set -> -1, else +1
+                const uint32_t hi = (x & k80) | one_hi;
+                if constexpr (sizeof(T) == 8) return (T) __hiloint2double((int) hi, 0);
+                else return (T) __uint_as_float(hi);
+            };
 #pragma unroll
-            for (int p = 0; p < ADMM_BP; ++p)
-                if (p < t.n_vpass) {  // v-update (qp_admm.h:132-142)
-                    const int slot = p * L + l;
-                    const int ml = t.v_maxlist[p];
-                    const uint32_t *lp = t.v_list + t.v_list_off[p] + l;
+            for (int p = 0; p < ADMM_BP; ++p) {
+                const int ml = (int) ((mlw_o >> (8 * p)) & 0xFFu);
+                if (p < t.n_vpass && ml > 0) {  // v-update (qp_admm.h:132-142); ml == 0: no variable of my wavefront here
                     T B = qreg[p] + (alpha / 2);
-                    for (int k = 0; k < ml; ++k) {
-                        const uint32_t ent = lp[(size_t) k * L];
-                        const int gs = (int) (ent & 0xFFFFFu);
-                        const int wp = (int) ((ent >> 20) & 3u);
-                        const int ty = (int) (ent >> 22);
 #pragma unroll
-                        for (int row = 0; row < 4; ++row) {
-                            const bool plus = (ty == 3 && row == 3) || (row == wp);
-                            B = __builtin_fma(plus ? (T) 1 : (T) -1, U[row * t.G_pad + gs], B);
+                    for (int k = 0; k < ADMM_VK; ++k)
+                        if (k < ml) {
+                            const uint32_t e = ent[p][k];
+                            const T4 u = *reinterpret_cast<const T4 *>(smem + ((e & 0xFFFFu) + lds0));
+                            B = X::fma(pm1(e), u.x, B);
+                            B = X::fma(pm1(e << k1), u.y, B);
+                            B = X::fma(pm1(e << k2), u.z, B);
+                            B = X::fma(pm1(e << k3), u.w, B);
                         }
+                    for (int k = ADMM_VK; k < ml; ++k) {  // lists longer than the register file holds
+                        const uint32_t e = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
+                        const T4 u = *reinterpret_cast<const T4 *>(smem + ((e & 0xFFFFu) + lds0));
+                        B = X::fma(pm1(e), u.x, B);
+                        B = X::fma(pm1(e << k1), u.y, B);
+                        B = X::fma(pm1(e << k2), u.z, B);
+                        B = X::fma(pm1(e << k3), u.w, B);
                     }
-                    T v = B * inv_coef[slot];
+                    T v = B * inv[p];
                     v = (v < (T) 0) ? (T) 0 : v;  // std::max(v, 0.0)
                     v = ((T) 1 < v) ? (T) 1 : v;  // std::min(v, 1.0)
-                    const int i = t.var_of_slot[slot];
-                    if (i >= 0) V[i] = v;
+                    if (vaddr[p] >= 0) *reinterpret_cast<T *>(smem + vaddr[p]) = v;
                 }
+            }
             __syncthreads();
             T sum2 = (T) 0;  // residual, multiplier and slack update (qp_admm.h:144-159)
 #pragma unroll
             for (int p = 0; p < ADMM_BP; ++p)
                 if (p < t.n_gpass) {
-                    const int gs = p * L + l;
-                    const int ty = t.grp_type[gs];
-                    T vm[3];
-                    int wp[3];
-                    bool have[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const uint32_t e = t.grp_mem[(size_t) k * t.G_pad + gs];
-                        have[k] = (e != 0xFFFFFFFFu);
-                        const int id = have[k] ? (int) (e & 0xFFFFFFu) : t.n_var;
-                        wp[k] = (int) (e >> 24);
-                        vm[k] = V[id];
-                    }
-                    const int rows = (ty == 3) ? 4 : ty;
-#pragma unroll
-                    for (int row = 0; row < 4; ++row) {
-                        T r = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const bool plus = (ty == 3 && row == 3) || (row == wp[k]);
-                            const T prod = plus ? vm[k] : -vm[k];
-                            r = have[k] ? (r - prod) : r;
-                        }
-                        const T wo = wreg[p][row];
-                        const T nwo = -wo;
-                        const T ylo = ((T) 0 < nwo) ? nwo : (T) 0;
-                        const T wn = r - ylo;
-                        const T z = ((T) 0 < wn) ? wn : (T) 0;
-                        if (row < rows) {
-                            wreg[p][row] = wn;
-                            const T nwn = -wn;
-                            const T yln = ((T) 0 < nwn) ? nwn : (T) 0;
-                            const T bb = (ty == 3 && row == 3) ? (T) 2 : (T) 0;
-                            U[row * t.G_pad + gs] = yln + mu * (z - bb);
-                            const T d = z - r;
-                            sum2 += d * d;
-                        }
+                    const uint32_t ty = (tys >> (2 * p)) & 3u;
+                    const uint32_t u3 = u_base + (uint32_t) ((p * L + l) * 4 + 3) * (uint32_t) sizeof(T);
+                    if ((gen_o >> p) & 1u) {  // wavefront-uniform
+                        if (ty != 0u)
+                            admm_group_update<T, EE, true>(smem, lds0, mem[p][0], mem[p][1], mem[p][2], u3, ty, mu, ylreg[p], sum2);
+                    } else {
+                        if (ty != 0u)
+                            admm_group_update<T, EE, false>(smem, lds0, mem[p][0], mem[p][1], mem[p][2], u3, ty, mu, ylreg[p], sum2);
                     }
                 }
-            sum2 = group_sum<64, T>(sum2);
-            if (lane == 0) red[wave] = sum2;
-            if (l < 4 && l >= (L >> 6)) red[l] = (T) 0;  // workgroups of fewer than 4 wavefronts
-            __syncthreads();
-            const T tot = ((red[0] + red[1]) + red[2]) + red[3];
             it += 1;
-            if (a.early_exit && tot < eps_stop) break;  // qp_admm.h:161-163 (identical in every thread)
+            if (EE) {
+                sum2 = wave_sum(sum2);
+                if (lane == 0) red[wave] = sum2;
+                if (l < 4 && l >= (L >> 6)) red[l] = (T) 0;  // workgroups of fewer than 4 wavefronts
+                __syncthreads();
+                const T tot = ((red[0] + red[1]) + red[2]) + red[3];
+                if (tot < eps_stop) break;  // qp_admm.h:161-163 (identical in every thread)
+            } else {
+                __syncthreads();
+            }
         }
         // ---- outputs (qp_admm.h:166-177) -----------------------------------------------------------------------
         for (int w = l; w < t.nwords; w += L) OB[w] = 0u;
@@ -628,40 +729,6 @@ __global__ void __launch_bounds__(ADMM_BLK) admm_block_kernel(const AdmmDevTable
             if (a.out_ok) a.out_ok[frame] = 1;
             if (a.out_iters) a.out_iters[frame] = it;
         }
-        if (MC) {
-            for (int c = l; c < t.m; c += L) {  // IsCodeword (experiment.h:111)
-                uint32_t sy = 0;
-                for (int e = t.row_ptr[c]; e < t.row_ptr[c + 1]; ++e) {
-                    const int v = t.edge_var[e];
-                    sy ^= (OB[v >> 5] >> (v & 31)) & 1u;
-                }
-                if (sy) flag_lds[0] = 1;
-            }
-            for (int w = l; w < t.nwords; w += L)
-                if (OB[w] != (cw ? cw[w] : 0u)) flag_lds[1] = 1;
-            __syncthreads();
-            if (l == 0) {
-                const bool is_cw = flag_lds[0] == 0, differ = flag_lds[1] != 0;
-                const bool correct = is_cw && !differ;
-                const int ham = ham_lds;
-                acc_correct += correct;
-                acc_pseudo += (is_cw && differ);
-                acc_total += 1;
-                acc_ham += ham;
-                acc_ham_ok += correct ? ham : 0;
-                acc_ham_wrong += correct ? 0 : ham;
-                acc_iters += it;
-            }
-        }
-    }
-    if (MC && l == 0 && acc_total) {
-        atomicAdd(&a.counters[MC_CORRECT], acc_correct);
-        atomicAdd(&a.counters[MC_PSEUDO], acc_pseudo);
-        atomicAdd(&a.counters[MC_TOTAL], acc_total);
-        atomicAdd(&a.counters[MC_HAM], acc_ham);
-        atomicAdd(&a.counters[MC_HAM_OK], acc_ham_ok);
-        atomicAdd(&a.counters[MC_HAM_WRONG], acc_ham_wrong);
-        atomicAdd(&a.counters[MC_ITERS], acc_iters);
     }
 }
 
@@ -804,6 +871,80 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         inv64[s] = -1.0 / (2 * Acoef);                        // qp_admm.h:126
     }
     bool ok = true;
+    if (d->blockmode) {
+        const uint32_t ts = d->f32 ? 4 : 8;
+        const uint32_t u_base = (uint32_t) t.V_pad * ts;
+        auto u_addr = [&](int gs, int row) { return u_base + ((uint32_t) gs * 4 + (uint32_t) row) * ts; };
+        if (u_addr(t.G_pad, 0) + (uint32_t) t.nwords * 4 > 0xFFFFu) {
+            err = "QP-ADMM frame state exceeds the 64 KiB the workgroup-per-frame kernel addresses";
+            admm_device_destroy(d);
+            return nullptr;
+        }
+        // slots: three-variable checks first, then the one- and two-variable ones (their wavefronts run the GENERIC
+        // instance of admm_group_update), then padding; slot n_grp is the all-zero slot list padding points to
+        std::vector<int> slot_of(A.n_grp), grp_of(t.G_pad, -1);
+        {
+            int sl = 0;
+            for (int pass = 0; pass < 2; pass++)
+                for (int g = 0; g < A.n_grp; g++)
+                    if ((A.grp_type[g] == 3) == (pass == 0)) {
+                        slot_of[g] = sl;
+                        grp_of[sl++] = g;
+                    }
+        }
+        std::vector<uint32_t> blk_mem((size_t) 3 * t.G_pad, 0);
+        std::vector<uint8_t> type_slot((size_t) t.G_pad, 0), blk_generic((size_t) t.n_gpass * 4, 0);
+        for (int sl = 0; sl < t.G_pad; sl++) {
+            const int g = grp_of[sl];
+            const int ty = g >= 0 ? A.grp_type[g] : 0;
+            type_slot[sl] = (uint8_t) ty;
+            if (ty == 1 || ty == 2) blk_generic[(size_t) (sl / L) * 4 + (sl % L) / 64] = 1;
+            bool row_used[4] = {false, false, false, false};
+            for (int k = 0; k < ty; k++) row_used[grp_mem[(size_t) k * t.G_pad + g] >> 24] = true;
+            for (int k = 0; k < 3; k++) {
+                uint32_t vid = (uint32_t) A.n_var, row = 0;  // absent member: the zero cell ...
+                if (k < ty) {
+                    const uint32_t e = grp_mem[(size_t) k * t.G_pad + g];
+                    vid = e & 0xFFFFFFu;
+                    row = e >> 24;
+                } else {  // ... and a row of this group that no member owns (it stays zero)
+                    while (row_used[row]) row++;
+                    row_used[row] = true;
+                }
+                blk_mem[(size_t) k * t.G_pad + sl] = (vid * ts) | (u_addr(sl, (int) row) << 16);
+            }
+        }
+        std::vector<uint32_t> blk_list(v_list.size(), u_addr(t.zero_gslot, 0));  // padding: the all-zero slot, coefficients +1
+        std::vector<int32_t> blk_mlw((size_t) t.n_vpass * 4, 0);
+        bool list_ok = true;
+        for (int s = 0; s < A.n_var; s++) {
+            const int i = vorder[s];
+            const int p_ = s / L, l = s % L;
+            blk_mlw[(size_t) p_ * 4 + l / 64] = std::max(blk_mlw[(size_t) p_ * 4 + l / 64], llen(i));
+            list_ok = list_ok && llen(i) <= 255;
+            for (int k = 0; k < llen(i); k++) {
+                const int ent = A.var_grp[A.var_ptr[i] + k];
+                const int g = ent >> 2, wpos = ent & 3, ty = A.grp_type[g];
+                uint32_t flags = 0;
+                for (int row = 0; row < 4; row++) {
+                    const bool plus = (ty == 3 && row == 3) || (row == wpos);
+                    if (!plus) flags |= 0x80000000u >> row;
+                }
+                blk_list[(size_t) v_list_off[p_] + (size_t) k * L + l] = u_addr(slot_of[g], 0) | flags;
+            }
+        }
+        if (!list_ok) {
+            err = "a variable in more than 255 checks: use lanes_per_frame 16/32/64 for QP-ADMM";
+            admm_device_destroy(d);
+            return nullptr;
+        }
+        t.blk_mem = (const uint32_t *) upload_vec(blk_mem, d->allocs, err);
+        t.blk_list = (const uint32_t *) upload_vec(blk_list, d->allocs, err);
+        t.blk_mlw = (const int32_t *) upload_vec(blk_mlw, d->allocs, err);
+        t.grp_type_slot = (const uint8_t *) upload_vec(type_slot, d->allocs, err);
+        t.blk_generic = (const uint8_t *) upload_vec(blk_generic, d->allocs, err);
+        ok = t.blk_mem && t.blk_list && t.blk_mlw && t.grp_type_slot && t.blk_generic;
+    }
     t.grp_mem = (const uint32_t *) upload_vec(grp_mem, d->allocs, err);
     t.grp_type = (const uint8_t *) upload_vec(grp_type, d->allocs, err);
     t.var_of_slot = (const int32_t *) upload_vec(var_of_slot, d->allocs, err);
@@ -818,7 +959,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     }
     t.row_ptr = (const int32_t *) upload_vec(c.row_ptr, d->allocs, err);
     t.edge_var = (const int32_t *) upload_vec(c.edge_var, d->allocs, err);
-    ok = t.grp_mem && t.grp_type && t.var_of_slot && t.v_maxlist && t.v_list_off && t.v_list && t.inv_coef && t.row_ptr && t.edge_var;
+    ok = ok && t.grp_mem && t.grp_type && t.var_of_slot && t.v_maxlist && t.v_list_off && t.v_list && t.inv_coef && t.row_ptr && t.edge_var;
     if (!ok) {
         admm_device_destroy(d);
         return nullptr;
@@ -837,9 +978,10 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
             return nullptr;
         }
         int per_cu = 0;
-        for (int mc = 0; mc < 2; mc++) {
-            const void *kp = d->f32 ? (mc ? (const void *) admm_block_kernel<float, true> : (const void *) admm_block_kernel<float, false>)
-                                    : (mc ? (const void *) admm_block_kernel<double, true> : (const void *) admm_block_kernel<double, false>);
+        for (int ee = 0; ee < 2; ee++) {  // kernel[0]: fixed sweep count, kernel[1]: with the residual stopping rule
+            const int mc = ee;
+            const void *kp = d->f32 ? (ee ? (const void *) admm_block_kernel<float, true> : (const void *) admm_block_kernel<float, false>)
+                                    : (ee ? (const void *) admm_block_kernel<double, true> : (const void *) admm_block_kernel<double, false>);
             d->kernel[mc] = kp;
             if (d->lds_block > 64 * 1024 &&
                 hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block) != hipSuccess) {
@@ -920,7 +1062,8 @@ static hipError_t admm_launch_t(AdmmDevice *d, const DecodeArgs &a, int grid, hi
     DecodeArgs aa = a;
     T alpha = (T) d->alpha, mu = (T) d->mu, eps = (T) d->eps;
     void *args[5] = {&tt, &aa, &alpha, &mu, &eps};
-    return hipLaunchKernel(d->kernel[a.mc ? 1 : 0], dim3(grid), dim3(d->block), args, d->lds_block, s);
+    const int which = d->blockmode ? (a.early_exit ? 1 : 0) : (a.mc ? 1 : 0);
+    return hipLaunchKernel(d->kernel[which], dim3(grid), dim3(d->block), args, d->lds_block, s);
 }
 
 hipError_t admm_launch(AdmmDevice *d, const DecodeArgs &a, hipStream_t s, std::string &err) {
@@ -932,6 +1075,10 @@ hipError_t admm_launch(AdmmDevice *d, const DecodeArgs &a, hipStream_t s, std::s
         int grid = (int) std::min<int64_t>((a.frames + 255) / 256, 4096);
         hipLaunchKernelGGL(admm_guard_kernel, dim3(grid), dim3(256), 0, s, a, d->t.nwords);
         return hipGetLastError();
+    }
+    if (d->blockmode && a.mc) {
+        err = "the workgroup-per-frame QP-ADMM kernel has no fused Monte-Carlo mode (use AWGN kernel -> decode -> classify)";
+        return hipErrorInvalidValue;
     }
     int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
     int grid = (int) std::min<int64_t>(blocks, d->grid_cap);
