@@ -9,7 +9,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libacg_ldpc_hip.so")
+# ACG_LDPC_LIB: developer override for A/B runs of differently-built libraries (tools/ab_build.sh)
+LIB_PATH = os.environ.get("ACG_LDPC_LIB") or os.path.join(HERE, "lib", "libacg_ldpc_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,7 @@ struct AdmmDevTables {
     const int32_t *blk_mlw;    // [n_vpass][4] longest list among the variables of (pass, wavefront)
     const uint8_t *grp_type_slot;  // [G_pad] group type per slot of the workgroup-per-frame kernel (type-3 groups first)
     const uint8_t *blk_generic;    // [n_gpass][4] 1 = (pass, wavefront) holds one- or two-variable checks
+    const int32_t *blk_cell;       // [n_vpass*L] V cell of the variable in that slot (-1 none)
     // syndrome (MC classification)
     const int32_t *row_ptr;
     const int32_t *edge_var;
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
 //  * the residual sum is only computed when the stopping rule is on (template EE), reduced with DPP lane
 //    exchanges instead of LDS permutes.
 constexpr int ADMM_BLK = 256;
-constexpr int ADMM_BP = 4;
+constexpr int ADMM_BP = 4;  // most passes any instance handles
 constexpr int ADMM_VK = 6;  // list entries per variable slot kept in registers (longer lists continue from global)
 
 template <typename T> struct AdmmVec;
@@ -514,6 +516,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     return ((r[0] + r[1]) + r[2]) + r[3];
 }
 
+// The four rows of a U slot (32 words apart inside its tile).  fp64: four ds_read_b64, spelled out because the
+// compiler would pair them into ds_read2_b64, which the LDS serves 16 lanes at a time at half the rate
+// (MI355X_MICROARCH.md, LDS table) — and the static placement (placement_optimise) is tuned for the 32-lane groups of ds_read_b64.
+__device__ __forceinline__ void admm_read_rows(unsigned char *smem, const uint32_t off, double &x, double &y, double &z, double &w) {
+    const uint32_t addr = off + (uint32_t) (uintptr_t) smem;  // LDS pointers are 32-bit offsets
+    asm("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:256\n\tds_read_b64 %2, %4 offset:512\n\tds_read_b64 %3, %4 offset:768\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(w)
+        : "v"(addr));
+}
+__device__ __forceinline__ void admm_read_rows(unsigned char *smem, const uint32_t off, float &x, float &y, float &z, float &w) {
+    const float *pu = reinterpret_cast<const float *>(smem + off);
+    x = pu[0];
+    y = pu[32];
+    z = pu[64];
+    w = pu[96];
+}
+
 // One constraint group (slot order, see above).  GENERIC also handles one- and two-variable checks, whose missing
 // slots must stay all-zero; the host puts those groups into passes/wavefronts flagged for the GENERIC instance so the
 // common instance carries no selects.  State yl[] = max(0, yl - r) of the previous sweep (qp_admm.h:157).
@@ -556,11 +576,12 @@ __device__ __forceinline__ void admm_group_update(unsigned char *smem, const uin
     *reinterpret_cast<T *>(smem + (u3_addr + lds0)) = u[3];
 }
 
-template <typename T, bool EE>
-__global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
+// BP = passes (of blockDim.x constraint groups / variables) the register-resident structure is sized for; fewer passes
+// = fewer registers = more wavefronts per SIMD (launch bound: 4, 5, 6 workgroups of 4 wavefronts per CU for BP = 4, 3, 2).
+template <typename T, bool EE, int BP>
+__global__ void __launch_bounds__(ADMM_BLK, 8 - BP) admm_block_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
                                                               const T mu, const T eps_stop) {
     using X = AdmmVec<T>;
-    typedef typename X::v4 T4;
     extern __shared__ __attribute__((aligned(32))) unsigned char smem[];
     const int L = blockDim.x;  // 128, 192 or 256 threads = one frame
     __shared__ T red[4];
@@ -572,10 +593,10 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
     const uint32_t u_base = (uint32_t) t.V_pad * (uint32_t) sizeof(T);
     uint32_t *OB = reinterpret_cast<uint32_t *>(smem + u_base + (size_t) 4 * t.G_pad * sizeof(T));
     // ---- loop-invariant per-thread structure -> registers ------------------------------------------------------------
-    uint32_t mem[ADMM_BP][3];  // member k of my group in pass p: LDS byte address of V[member] | address of U[group][wpos k] << 16
+    uint32_t mem[BP][3];  // member k of my group in pass p: LDS byte address of V[member] | address of U[group][wpos k] << 16
     uint32_t tys = 0;          // group type of pass p at bits 2p..2p+1 (0 = padding slot)
 #pragma unroll
-    for (int p = 0; p < ADMM_BP; ++p) {
+    for (int p = 0; p < BP; ++p) {
         mem[p][0] = mem[p][1] = mem[p][2] = 0;
         if (p < t.n_gpass) {
             const int gs = p * L + l;
@@ -584,14 +605,14 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
             for (int k = 0; k < 3; ++k) mem[p][k] = t.blk_mem[(size_t) k * t.G_pad + gs];
         }
     }
-    uint32_t ent[ADMM_BP][ADMM_VK];  // list entries: LDS byte address of U[group][0] | "coefficient is -1" flags, row r at bit 31-r
+    uint32_t ent[BP][ADMM_VK];  // list entries: LDS byte address of U[group][0] | "coefficient is -1" flags, row r at bit 31-r
     uint32_t mlw_pk = 0;             // list length of (pass p, my wavefront) at bits 8p..8p+7
     uint32_t gen_pk = 0;             // bit p: (pass p, my wavefront) holds one- or two-variable checks
-    int vaddr[ADMM_BP];              // LDS byte address of my variable in pass p, -1 = none
-    T inv[ADMM_BP];
+    int vaddr[BP];              // LDS byte address of my variable in pass p, -1 = none
+    T inv[BP];
     const T *inv_coef = reinterpret_cast<const T *>(t.inv_coef);
 #pragma unroll
-    for (int p = 0; p < ADMM_BP; ++p) {
+    for (int p = 0; p < BP; ++p) {
         vaddr[p] = -1;
         inv[p] = (T) 0;
 #pragma unroll
@@ -600,8 +621,8 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
         if (p < t.n_vpass) {
             const int ml = t.blk_mlw[p * 4 + wave];
             mlw_pk |= (uint32_t) ml << (8 * p);
-            const int i = t.var_of_slot[p * L + l];
-            vaddr[p] = (i >= 0) ? i * (int) sizeof(T) : -1;
+            const int cell = t.blk_cell[p * L + l];
+            vaddr[p] = (cell >= 0) ? cell * (int) sizeof(T) : -1;
             inv[p] = inv_coef[p * L + l];
 #pragma unroll
             for (int k = 0; k < ADMM_VK; ++k)
@@ -610,7 +631,10 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
     }
     mlw_pk = (uint32_t) __builtin_amdgcn_readfirstlane((int) mlw_pk);
     gen_pk = (uint32_t) __builtin_amdgcn_readfirstlane((int) gen_pk);
-    T ylreg[ADMM_BP][4], qreg[ADMM_BP];
+    T ylreg[BP][4], qreg[BP];
+    // U is tiled 32 slots x 4 rows: my slot in pass p has row 3 at u3_0 + p * u3_step, row r 32 words before per row
+    const uint32_t u3_0 = u_base + (uint32_t) ((l >> 5) * 128 + 96 + (l & 31)) * (uint32_t) sizeof(T);
+    const uint32_t u3_step = (uint32_t) L * 4u * (uint32_t) sizeof(T);
 
     for (;;) {
         __syncthreads();
@@ -620,11 +644,11 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
         if (frame >= a.frames) break;
         // ---- start of a frame --------------------------------------------------------------------------------
 #pragma unroll
-        for (int p = 0; p < ADMM_BP; ++p) {
+        for (int p = 0; p < BP; ++p) {
             T q = (T) 0;  // auxiliaries: q = 0 (qp_admm.h:24)
             if (p < t.n_vpass) {
-                const int i = vaddr[p] / (int) sizeof(T);
-                if (vaddr[p] >= 0 && i < t.n) {
+                const int i = t.var_of_slot[p * L + l];
+                if (i >= 0 && i < t.n) {
                     if (a.y_is_f64) q = (T) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + i] / a.var);
                     else q = (T) (2 * (double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + i] / a.var);
                 }
@@ -633,15 +657,13 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
         }
         for (int w = l; w < t.V_pad; w += L) V[w] = (T) 0;
 #pragma unroll
-        for (int p = 0; p < ADMM_BP; ++p) {
+        for (int p = 0; p < BP; ++p) {
 #pragma unroll
             for (int row = 0; row < 4; ++row) ylreg[p][row] = (T) 0;  // z = yl = 0 (qp_admm.h:120-121)
             if (p < t.n_gpass) {
-                const int gs = p * L + l;
-                T4 u0;
-                u0.x = u0.y = u0.z = (T) 0 + mu * ((T) 0 - (T) 0);
-                u0.w = (((tys >> (2 * p)) & 3u) == 3u) ? (T) 0 + mu * ((T) 0 - (T) 2) : (T) 0 + mu * ((T) 0 - (T) 0);
-                *reinterpret_cast<T4 *>(smem + u_base + (size_t) gs * sizeof(T4)) = u0;
+                T *pu = reinterpret_cast<T *>(smem + u3_0 + (uint32_t) p * u3_step) - 96;  // U[slot][row] = pu[32 * row]
+                pu[0] = pu[32] = pu[64] = (T) 0 + mu * ((T) 0 - (T) 0);
+                pu[96] = (((tys >> (2 * p)) & 3u) == 3u) ? (T) 0 + mu * ((T) 0 - (T) 2) : (T) 0 + mu * ((T) 0 - (T) 0);
             }
         }
         __syncthreads();
@@ -662,7 +684,7 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
                 else return (T) __uint_as_float(hi);
             };
 #pragma unroll
-            for (int p = 0; p < ADMM_BP; ++p) {
+            for (int p = 0; p < BP; ++p) {
                 const int ml = (int) ((mlw_o >> (8 * p)) & 0xFFu);
                 if (p < t.n_vpass && ml > 0) {  // v-update (qp_admm.h:132-142); ml == 0: no variable of my wavefront here
                     T B = qreg[p] + (alpha / 2);
@@ -670,19 +692,21 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
                     for (int k = 0; k < ADMM_VK; ++k)
                         if (k < ml) {
                             const uint32_t e = ent[p][k];
-                            const T4 u = *reinterpret_cast<const T4 *>(smem + ((e & 0xFFFFu) + lds0));
-                            B = X::fma(pm1(e), u.x, B);
-                            B = X::fma(pm1(e << k1), u.y, B);
-                            B = X::fma(pm1(e << k2), u.z, B);
-                            B = X::fma(pm1(e << k3), u.w, B);
+                            T ux, uy, uz, uw;
+                            admm_read_rows(smem, (e & 0xFFFFu) + lds0, ux, uy, uz, uw);
+                            B = X::fma(pm1(e), ux, B);
+                            B = X::fma(pm1(e << k1), uy, B);
+                            B = X::fma(pm1(e << k2), uz, B);
+                            B = X::fma(pm1(e << k3), uw, B);
                         }
                     for (int k = ADMM_VK; k < ml; ++k) {  // lists longer than the register file holds
                         const uint32_t e = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
-                        const T4 u = *reinterpret_cast<const T4 *>(smem + ((e & 0xFFFFu) + lds0));
-                        B = X::fma(pm1(e), u.x, B);
-                        B = X::fma(pm1(e << k1), u.y, B);
-                        B = X::fma(pm1(e << k2), u.z, B);
-                        B = X::fma(pm1(e << k3), u.w, B);
+                        T ux, uy, uz, uw;
+                        admm_read_rows(smem, (e & 0xFFFFu) + lds0, ux, uy, uz, uw);
+                        B = X::fma(pm1(e), ux, B);
+                        B = X::fma(pm1(e << k1), uy, B);
+                        B = X::fma(pm1(e << k2), uz, B);
+                        B = X::fma(pm1(e << k3), uw, B);
                     }
                     T v = B * inv[p];
                     v = (v < (T) 0) ? (T) 0 : v;  // std::max(v, 0.0)
@@ -693,10 +717,10 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
             __syncthreads();
             T sum2 = (T) 0;  // residual, multiplier and slack update (qp_admm.h:144-159)
 #pragma unroll
-            for (int p = 0; p < ADMM_BP; ++p)
+            for (int p = 0; p < BP; ++p)
                 if (p < t.n_gpass) {
                     const uint32_t ty = (tys >> (2 * p)) & 3u;
-                    const uint32_t u3 = u_base + (uint32_t) ((p * L + l) * 4 + 3) * (uint32_t) sizeof(T);
+                    const uint32_t u3 = u3_0 + (uint32_t) p * u3_step;
                     if ((gen_o >> p) & 1u) {  // wavefront-uniform
                         if (ty != 0u)
                             admm_group_update<T, EE, true>(smem, lds0, mem[p][0], mem[p][1], mem[p][2], u3, ty, mu, ylreg[p], sum2);
@@ -720,8 +744,12 @@ __global__ void __launch_bounds__(ADMM_BLK, 4) admm_block_kernel(const AdmmDevTa
         // ---- outputs (qp_admm.h:166-177) -----------------------------------------------------------------------
         for (int w = l; w < t.nwords; w += L) OB[w] = 0u;
         __syncthreads();
-        for (int v = l; v < t.n; v += L)
-            if (!(V[v] <= (T) 0.5)) atomicOr(&OB[v >> 5], 1u << (v & 31));
+#pragma unroll
+        for (int p = 0; p < BP; ++p)
+            if (p < t.n_vpass) {  // every thread reports the variables it owns (V is indexed by cell, not by variable id)
+                const int i = t.var_of_slot[p * L + l];
+                if (i >= 0 && i < t.n && !(*reinterpret_cast<const T *>(smem + vaddr[p]) <= (T) 0.5)) atomicOr(&OB[i >> 5], 1u << (i & 31));
+            }
         __syncthreads();
         if (a.out_bits)
             for (int w = l; w < t.nwords; w += L) a.out_bits[(size_t) frame * t.nwords + w] = OB[w];
@@ -760,6 +788,89 @@ static const void *admm_kernel_ptr(int f32, int L, bool mc, bool reg) {
     return admm_ptr<double, 16, 0>(mc);
 }
 
+// Static placement against LDS bank conflicts.  A wave64 LDS access is served in fixed lane groups and takes as many
+// LDS cycles as the busiest bank has distinct addresses (MI355X_MICROARCH.md, LDS).  Which group slot / variable cell a
+// lane touches in every instruction of the sweep is known when the decoder is created, so the two free permutations
+// (constraint group -> U slot, variable -> V cell) are chosen to spread every lane group over the banks:
+// items = groups or variables, position = slot or cell, a "set" = the items one lane group touches with one
+// instruction, bank class = position mod `modulus`.  Objective: sum over sets of sum over classes of count^2
+// (minimal when every class is hit at most once); deterministic random swaps, accepted when not worse.
+struct PlacementSet {
+    std::vector<int> items;
+    int modulus;
+};
+
+static long placement_optimise(std::vector<int> &pos_of_item, const int n_pos, const std::vector<PlacementSet> &sets,
+                               const int rounds, std::vector<long> *per_set_max = nullptr) {
+    const int n_items = (int) pos_of_item.size();
+    std::vector<int> item_at(n_pos, -1);
+    for (int i = 0; i < n_items; i++) item_at[pos_of_item[i]] = i;
+    std::vector<std::vector<int>> sets_of(n_items);
+    std::vector<std::vector<int>> cnt(sets.size());
+    long total = 0;
+    for (size_t si = 0; si < sets.size(); si++) {
+        cnt[si].assign(sets[si].modulus, 0);
+        for (int it : sets[si].items) {
+            sets_of[it].push_back((int) si);
+            const int c = pos_of_item[it] % sets[si].modulus;
+            total += 2 * cnt[si][c] + 1;
+            cnt[si][c]++;
+        }
+    }
+    auto move = [&](int it, int newpos) {  // updates counts and `total`
+        for (int si : sets_of[it]) {
+            const int m = sets[si].modulus, co = pos_of_item[it] % m, cn = newpos % m;
+            if (co == cn) continue;
+            total -= 2 * cnt[si][co] - 1;
+            cnt[si][co]--;
+            total += 2 * cnt[si][cn] + 1;
+            cnt[si][cn]++;
+        }
+        pos_of_item[it] = newpos;
+    };
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        rng ^= rng << 13;
+        rng ^= rng >> 7;
+        rng ^= rng << 17;
+        return rng;
+    };
+    if (n_items > 1 && n_pos > 1)
+        for (long r = 0; r < (long) rounds * n_items; r++) {
+            const int a = (int) (next() % (uint64_t) n_items);
+            const int q = (int) (next() % (uint64_t) n_pos), pa = pos_of_item[a];
+            if (q == pa) continue;
+            const int b = item_at[q];
+            const long before = total;
+            move(a, q);
+            if (b >= 0) move(b, pa);
+            if (total > before) {  // revert
+                if (b >= 0) move(b, q);
+                move(a, pa);
+            } else {
+                item_at[q] = a;
+                item_at[pa] = b;
+            }
+        }
+    if (per_set_max) {
+        per_set_max->clear();
+        for (size_t si = 0; si < sets.size(); si++) per_set_max->push_back(*std::max_element(cnt[si].begin(), cnt[si].end()));
+    }
+    return total;
+}
+
+template <typename T, bool EE>
+static const void *admm_block_ptr_t(int passes) {
+    if (passes <= 2) return (const void *) admm_block_kernel<T, EE, 2>;
+    if (passes == 3) return (const void *) admm_block_kernel<T, EE, 3>;
+    return (const void *) admm_block_kernel<T, EE, 4>;
+}
+
+static const void *admm_block_ptr(int f32, bool ee, int passes) {
+    if (f32) return ee ? admm_block_ptr_t<float, true>(passes) : admm_block_ptr_t<float, false>(passes);
+    return ee ? admm_block_ptr_t<double, true>(passes) : admm_block_ptr_t<double, false>(passes);
+}
+
 template <typename T>
 static void *upload_vec(const std::vector<T> &h, std::vector<void *> &allocs, std::string &err) {
     void *d = nullptr;
@@ -784,15 +895,26 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     d->eps = p.eps_stop;
     d->f32 = (p.precision == ACG_LDPC_PREC_F32) ? 1 : 0;
     int L = p.lanes_per_frame ? p.lanes_per_frame : 64;
-    // auto / 256: one workgroup (128, 192 or 256 threads) per frame when the problem has at most 4 passes of it;
-    // the size with the fewest padded group slots wins (LDS per frame = 4 words per slot), ties go to the larger
+    // auto / 256: one workgroup (128, 192 or 256 threads) per frame when the problem has at most 4 passes of it.
+    // Choice: most workgroups resident per CU (LDS: 160 KiB; registers: 8 - passes workgroups of 4 wavefronts, see
+    // admm_block_kernel) per pass of serial work; ties go to the larger workgroup.
     const bool can_block = (A.n_grp + 1 <= ADMM_BP * ADMM_BLK) && (A.n_var <= ADMM_BP * ADMM_BLK);
     if ((p.lanes_per_frame == 0 || p.lanes_per_frame == ADMM_BLK) && can_block) {
-        int bestL = ADMM_BLK, best_pad = ((A.n_grp + 1 + ADMM_BLK - 1) / ADMM_BLK) * ADMM_BLK;
-        for (int cand : {192, 128}) {
+        int bestL = 0;
+        double best_score = -1;
+        const char *force = getenv("ACG_ADMM_BLOCK_L");  // developer A/B only
+        for (int cand : {256, 192, 128}) {
             const int gp = (A.n_grp + 1 + cand - 1) / cand, vp = (A.n_var + cand - 1) / cand;
-            if (gp <= ADMM_BP && vp <= ADMM_BP && gp * cand < best_pad) {
-                best_pad = gp * cand;
+            const int passes = std::max(std::max(gp, vp), 2);
+            if (passes > ADMM_BP) continue;
+            const size_t ts_ = (p.precision == ACG_LDPC_PREC_F32) ? 4 : 8;
+            const size_t lds = (size_t) (4 * gp * cand + A.n_var + 4) * ts_ + 64;
+            const int by_lds = (int) ((160 * 1024) / lds);
+            const int by_reg = ((8 - passes) * 4) / (cand / 64);
+            double score = (double) std::min(by_lds, by_reg) / passes;
+            if (force && atoi(force) == cand) score = 1e9;
+            if (score > best_score) {
+                best_score = score;
                 bestL = cand;
             }
         }
@@ -874,7 +996,11 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     if (d->blockmode) {
         const uint32_t ts = d->f32 ? 4 : 8;
         const uint32_t u_base = (uint32_t) t.V_pad * ts;
-        auto u_addr = [&](int gs, int row) { return u_base + ((uint32_t) gs * 4 + (uint32_t) row) * ts; };
+        // U is tiled: 32 slots x 4 rows per tile, row-major inside a tile, so the four rows of a slot are a fixed
+        // 32-word stride apart (immediate offsets) and the bank of every access is slot mod 32
+        auto u_addr = [&](int gs, int row) {
+            return u_base + (((uint32_t) gs >> 5) * 128u + (uint32_t) row * 32u + ((uint32_t) gs & 31u)) * ts;
+        };
         if (u_addr(t.G_pad, 0) + (uint32_t) t.nwords * 4 > 0xFFFFu) {
             err = "QP-ADMM frame state exceeds the 64 KiB the workgroup-per-frame kernel addresses";
             admm_device_destroy(d);
@@ -883,14 +1009,71 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         // slots: three-variable checks first, then the one- and two-variable ones (their wavefronts run the GENERIC
         // instance of admm_group_update), then padding; slot n_grp is the all-zero slot list padding points to
         std::vector<int> slot_of(A.n_grp), grp_of(t.G_pad, -1);
+        int n3 = 0;
         {
             int sl = 0;
-            for (int pass = 0; pass < 2; pass++)
+            for (int pass = 0; pass < 2; pass++) {
                 for (int g = 0; g < A.n_grp; g++)
-                    if ((A.grp_type[g] == 3) == (pass == 0)) {
-                        slot_of[g] = sl;
-                        grp_of[sl++] = g;
+                    if ((A.grp_type[g] == 3) == (pass == 0)) slot_of[g] = sl++;
+                if (pass == 0) n3 = sl;
+            }
+        }
+        const bool tune = getenv("ACG_ADMM_NO_PLACEMENT") == nullptr;  // developer A/B only
+        if (tune && n3 > 1) {
+            // v-update: lanes [32h, 32h+32) of (pass, wavefront) read entry k of their variables: ds_read_b64/_b32, bank = slot mod 32
+            std::vector<int> item_of_grp(A.n_grp, -1), pos3;
+            for (int g = 0; g < A.n_grp; g++)
+                if (A.grp_type[g] == 3) {
+                    item_of_grp[g] = (int) pos3.size();
+                    pos3.push_back(slot_of[g]);
+                }
+            std::vector<PlacementSet> sets;
+            for (int p_ = 0; p_ < t.n_vpass; p_++)
+                for (int h = 0; h < L / 32; h++)
+                    for (int k = 0; k < v_maxlist[p_]; k++) {
+                        PlacementSet ps;
+                        ps.modulus = 32;
+                        for (int l = 32 * h; l < 32 * h + 32; l++) {
+                            const int sidx = p_ * L + l;
+                            if (sidx >= A.n_var) continue;
+                            const int i = vorder[sidx];
+                            if (k >= llen(i)) continue;
+                            const int g = A.var_grp[A.var_ptr[i] + k] >> 2;
+                            if (item_of_grp[g] >= 0) ps.items.push_back(item_of_grp[g]);
+                        }
+                        if (ps.items.size() > 1) sets.push_back(std::move(ps));
                     }
+            placement_optimise(pos3, n3, sets, 300);
+            for (int g = 0; g < A.n_grp; g++)
+                if (item_of_grp[g] >= 0) slot_of[g] = pos3[item_of_grp[g]];
+        }
+        for (int g = 0; g < A.n_grp; g++) grp_of[slot_of[g]] = g;
+        // variable -> V cell
+        std::vector<int> cell_of(A.n_var);
+        for (int i = 0; i < A.n_var; i++) cell_of[i] = i;
+        if (tune && A.n_var > 1) {
+            std::vector<PlacementSet> sets;
+            // row phase: lanes [32h, 32h+32) of a group pass read member k of their groups: bank = cell mod 32
+            for (int base = 0; base < t.G_pad; base += 32)
+                for (int k = 0; k < 3; k++) {
+                    PlacementSet ps;
+                    ps.modulus = 32;
+                    for (int sl = base; sl < base + 32; sl++) {
+                        const int g = grp_of[sl];
+                        if (g >= 0 && k < A.grp_type[g]) ps.items.push_back((int) (grp_mem[(size_t) k * t.G_pad + g] & 0xFFFFFFu));
+                    }
+                    if (ps.items.size() > 1) sets.push_back(std::move(ps));
+                }
+            // v-update: each lane stores its variable: ds_write_b64 is served 16 lanes at a time (16 bank pairs),
+            // ds_write_b32 32 lanes at a time
+            const int wl = d->f32 ? 32 : 16;
+            for (int base = 0; base < A.n_var; base += wl) {
+                PlacementSet ps;
+                ps.modulus = wl;
+                for (int sidx = base; sidx < std::min(base + wl, A.n_var); sidx++) ps.items.push_back(vorder[sidx]);
+                if (ps.items.size() > 1) sets.push_back(std::move(ps));
+            }
+            placement_optimise(cell_of, A.n_var, sets, 300);
         }
         std::vector<uint32_t> blk_mem((size_t) 3 * t.G_pad, 0);
         std::vector<uint8_t> type_slot((size_t) t.G_pad, 0), blk_generic((size_t) t.n_gpass * 4, 0);
@@ -911,15 +1094,17 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
                     while (row_used[row]) row++;
                     row_used[row] = true;
                 }
-                blk_mem[(size_t) k * t.G_pad + sl] = (vid * ts) | (u_addr(sl, (int) row) << 16);
+                const uint32_t cell = vid < (uint32_t) A.n_var ? (uint32_t) cell_of[vid] : vid;
+                blk_mem[(size_t) k * t.G_pad + sl] = (cell * ts) | (u_addr(sl, (int) row) << 16);
             }
         }
         std::vector<uint32_t> blk_list(v_list.size(), u_addr(t.zero_gslot, 0));  // padding: the all-zero slot, coefficients +1
-        std::vector<int32_t> blk_mlw((size_t) t.n_vpass * 4, 0);
+        std::vector<int32_t> blk_mlw((size_t) t.n_vpass * 4, 0), blk_cell((size_t) t.n_vpass * L, -1);
         bool list_ok = true;
         for (int s = 0; s < A.n_var; s++) {
             const int i = vorder[s];
             const int p_ = s / L, l = s % L;
+            blk_cell[s] = cell_of[i];
             blk_mlw[(size_t) p_ * 4 + l / 64] = std::max(blk_mlw[(size_t) p_ * 4 + l / 64], llen(i));
             list_ok = list_ok && llen(i) <= 255;
             for (int k = 0; k < llen(i); k++) {
@@ -943,7 +1128,8 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         t.blk_mlw = (const int32_t *) upload_vec(blk_mlw, d->allocs, err);
         t.grp_type_slot = (const uint8_t *) upload_vec(type_slot, d->allocs, err);
         t.blk_generic = (const uint8_t *) upload_vec(blk_generic, d->allocs, err);
-        ok = t.blk_mem && t.blk_list && t.blk_mlw && t.grp_type_slot && t.blk_generic;
+        t.blk_cell = (const int32_t *) upload_vec(blk_cell, d->allocs, err);
+        ok = t.blk_mem && t.blk_list && t.blk_mlw && t.grp_type_slot && t.blk_generic && t.blk_cell;
     }
     t.grp_mem = (const uint32_t *) upload_vec(grp_mem, d->allocs, err);
     t.grp_type = (const uint8_t *) upload_vec(grp_type, d->allocs, err);
@@ -980,8 +1166,8 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         int per_cu = 0;
         for (int ee = 0; ee < 2; ee++) {  // kernel[0]: fixed sweep count, kernel[1]: with the residual stopping rule
             const int mc = ee;
-            const void *kp = d->f32 ? (ee ? (const void *) admm_block_kernel<float, true> : (const void *) admm_block_kernel<float, false>)
-                                    : (ee ? (const void *) admm_block_kernel<double, true> : (const void *) admm_block_kernel<double, false>);
+            const int passes = std::max(std::max(t.n_gpass, t.n_vpass), 2);
+            const void *kp = admm_block_ptr(d->f32, ee != 0, passes);
             d->kernel[mc] = kp;
             if (d->lds_block > 64 * 1024 &&
                 hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block) != hipSuccess) {
@@ -1062,7 +1248,8 @@ static hipError_t admm_launch_t(AdmmDevice *d, const DecodeArgs &a, int grid, hi
     DecodeArgs aa = a;
     T alpha = (T) d->alpha, mu = (T) d->mu, eps = (T) d->eps;
     void *args[5] = {&tt, &aa, &alpha, &mu, &eps};
-    const int which = d->blockmode ? (a.early_exit ? 1 : 0) : (a.mc ? 1 : 0);
+    // eps_stop <= 0: the residual (a sum of squares) is never below it, so the instance without the residual is exact
+    const int which = d->blockmode ? ((a.early_exit && d->eps > 0) ? 1 : 0) : (a.mc ? 1 : 0);
     return hipLaunchKernel(d->kernel[which], dim3(grid), dim3(d->block), args, d->lds_block, s);
 }
 

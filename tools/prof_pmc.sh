@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 tag=$1; shift
-rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/prof_pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/prof_pmc_$tag.log 2>&1
+rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/prof_pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS} > gpurun_out/prof_pmc_$tag.log 2>&1
 echo "rc=$?" >> gpurun_out/prof_pmc_$tag.log
 tail -2 gpurun_out/prof_pmc_$tag.log
 f=$(find gpurun_out/prof_pmc_$tag -name "*counter_collection.csv" | head -1)
