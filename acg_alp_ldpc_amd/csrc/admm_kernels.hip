@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -788,75 +789,15 @@ static const void *admm_kernel_ptr(int f32, int L, bool mc, bool reg) {
     return admm_ptr<double, 16, 0>(mc);
 }
 
-// Static placement against LDS bank conflicts.  A wave64 LDS access is served in fixed lane groups and takes as many
-// LDS cycles as the busiest bank has distinct addresses (MI355X_MICROARCH.md, LDS).  Which group slot / variable cell a
-// lane touches in every instruction of the sweep is known when the decoder is created, so the two free permutations
-// (constraint group -> U slot, variable -> V cell) are chosen to spread every lane group over the banks:
-// items = groups or variables, position = slot or cell, a "set" = the items one lane group touches with one
-// instruction, bank class = position mod `modulus`.  Objective: sum over sets of sum over classes of count^2
-// (minimal when every class is hit at most once); deterministic random swaps, accepted when not worse.
-struct PlacementSet {
-    std::vector<int> items;
-    int modulus;
-};
-
-static long placement_optimise(std::vector<int> &pos_of_item, const int n_pos, const std::vector<PlacementSet> &sets,
-                               const int rounds, std::vector<long> *per_set_max = nullptr) {
-    const int n_items = (int) pos_of_item.size();
-    std::vector<int> item_at(n_pos, -1);
-    for (int i = 0; i < n_items; i++) item_at[pos_of_item[i]] = i;
-    std::vector<std::vector<int>> sets_of(n_items);
-    std::vector<std::vector<int>> cnt(sets.size());
-    long total = 0;
-    for (size_t si = 0; si < sets.size(); si++) {
-        cnt[si].assign(sets[si].modulus, 0);
-        for (int it : sets[si].items) {
-            sets_of[it].push_back((int) si);
-            const int c = pos_of_item[it] % sets[si].modulus;
-            total += 2 * cnt[si][c] + 1;
-            cnt[si][c]++;
-        }
-    }
-    auto move = [&](int it, int newpos) {  // updates counts and `total`
-        for (int si : sets_of[it]) {
-            const int m = sets[si].modulus, co = pos_of_item[it] % m, cn = newpos % m;
-            if (co == cn) continue;
-            total -= 2 * cnt[si][co] - 1;
-            cnt[si][co]--;
-            total += 2 * cnt[si][cn] + 1;
-            cnt[si][cn]++;
-        }
-        pos_of_item[it] = newpos;
-    };
-    uint64_t rng = 0x9E3779B97F4A7C15ull;
-    auto next = [&]() {
-        rng ^= rng << 13;
-        rng ^= rng >> 7;
-        rng ^= rng << 17;
-        return rng;
-    };
-    if (n_items > 1 && n_pos > 1)
-        for (long r = 0; r < (long) rounds * n_items; r++) {
-            const int a = (int) (next() % (uint64_t) n_items);
-            const int q = (int) (next() % (uint64_t) n_pos), pa = pos_of_item[a];
-            if (q == pa) continue;
-            const int b = item_at[q];
-            const long before = total;
-            move(a, q);
-            if (b >= 0) move(b, pa);
-            if (total > before) {  // revert
-                if (b >= 0) move(b, q);
-                move(a, pa);
-            } else {
-                item_at[q] = a;
-                item_at[pa] = b;
-            }
-        }
-    if (per_set_max) {
-        per_set_max->clear();
-        for (size_t si = 0; si < sets.size(); si++) per_set_max->push_back(*std::max_element(cnt[si].begin(), cnt[si].end()));
-    }
-    return total;
+// ACG_ADMM_PLACEMENT_DEBUG=1: LDS cycles (sum over sets of the busiest bank) vs the conflict-free count
+static void placement_report(const char *what, std::vector<int> &pos, const int n_pos, const std::vector<PlacementSet> &sets) {
+    if (!getenv("ACG_ADMM_PLACEMENT_DEBUG")) return;
+    std::vector<long> mx;
+    std::vector<int> copy = pos;
+    placement_optimise(copy, n_pos, sets, 0, &mx);
+    long cyc = 0;
+    for (long m : mx) cyc += m;
+    fprintf(stderr, "[acg_ldpc] placement %s: %zu sets, %ld LDS cycles (conflict-free %zu)\n", what, sets.size(), cyc, sets.size());
 }
 
 template <typename T, bool EE>
@@ -1043,7 +984,9 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
                         }
                         if (ps.items.size() > 1) sets.push_back(std::move(ps));
                     }
-            placement_optimise(pos3, n3, sets, 300);
+            placement_report("U slots before", pos3, n3, sets);
+            placement_optimise(pos3, n3, sets, 800);
+            placement_report("U slots after", pos3, n3, sets);
             for (int g = 0; g < A.n_grp; g++)
                 if (item_of_grp[g] >= 0) slot_of[g] = pos3[item_of_grp[g]];
         }
@@ -1073,7 +1016,9 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
                 for (int sidx = base; sidx < std::min(base + wl, A.n_var); sidx++) ps.items.push_back(vorder[sidx]);
                 if (ps.items.size() > 1) sets.push_back(std::move(ps));
             }
-            placement_optimise(cell_of, A.n_var, sets, 300);
+            placement_report("V cells before", cell_of, A.n_var, sets);
+            placement_optimise(cell_of, A.n_var, sets, 800);
+            placement_report("V cells after", cell_of, A.n_var, sets);
         }
         std::vector<uint32_t> blk_mem((size_t) 3 * t.G_pad, 0);
         std::vector<uint8_t> type_slot((size_t) t.G_pad, 0), blk_generic((size_t) t.n_gpass * 4, 0);

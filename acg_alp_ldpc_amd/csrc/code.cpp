@@ -5,6 +5,7 @@
 #include "ldpc_internal.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -317,5 +318,69 @@ void admm_layout_build(Code &c) {
     }
     if (a.n_var == 0) a.e_min = a.e_max = 0;
 }
+
+long placement_optimise(std::vector<int> &pos_of_item, const int n_pos, const std::vector<PlacementSet> &sets,
+                               const int rounds, std::vector<long> *per_set_max) {
+    const int n_items = (int) pos_of_item.size();
+    std::vector<int> item_at(n_pos, -1);
+    for (int i = 0; i < n_items; i++) item_at[pos_of_item[i]] = i;
+    std::vector<std::vector<int>> sets_of(n_items);
+    std::vector<std::vector<int>> cnt(sets.size());
+    long total = 0;
+    for (size_t si = 0; si < sets.size(); si++) {
+        cnt[si].assign(sets[si].modulus, 0);
+        for (int it : sets[si].items) {
+            sets_of[it].push_back((int) si);
+            const int c = pos_of_item[it] % sets[si].modulus;
+            total += 2 * cnt[si][c] + 1;
+            cnt[si][c]++;
+        }
+    }
+    auto move = [&](int it, int newpos) {  // updates counts and `total`
+        for (int si : sets_of[it]) {
+            const int m = sets[si].modulus, co = pos_of_item[it] % m, cn = newpos % m;
+            if (co == cn) continue;
+            total -= 2 * cnt[si][co] - 1;
+            cnt[si][co]--;
+            total += 2 * cnt[si][cn] + 1;
+            cnt[si][cn]++;
+        }
+        pos_of_item[it] = newpos;
+    };
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        rng ^= rng << 13;
+        rng ^= rng >> 7;
+        rng ^= rng << 17;
+        return rng;
+    };
+    // simulated annealing, temperature 1.5 -> 0.05 (in units of the objective), deterministic
+    const long moves = (long) rounds * n_items;
+    if (n_items > 1 && n_pos > 1)
+        for (long r = 0; r < moves; r++) {
+            const double T = 1.5 * std::pow(0.05 / 1.5, (double) r / (double) moves);
+            const int a = (int) (next() % (uint64_t) n_items);
+            const int q = (int) (next() % (uint64_t) n_pos), pa = pos_of_item[a];
+            if (q == pa) continue;
+            const int b = item_at[q];
+            const long before = total;
+            move(a, q);
+            if (b >= 0) move(b, pa);
+            const long delta = total - before;
+            if (delta > 0 && (double) (next() >> 11) * (1.0 / 9007199254740992.0) >= std::exp(-(double) delta / T)) {  // revert
+                if (b >= 0) move(b, q);
+                move(a, pa);
+            } else {
+                item_at[q] = a;
+                item_at[pa] = b;
+            }
+        }
+    if (per_set_max) {
+        per_set_max->clear();
+        for (size_t si = 0; si < sets.size(); si++) per_set_max->push_back(*std::max_element(cnt[si].begin(), cnt[si].end()));
+    }
+    return total;
+}
+
 
 }  // namespace acg

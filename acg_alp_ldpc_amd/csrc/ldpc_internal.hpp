@@ -70,4 +70,18 @@ bool code_is_codeword(const Code &c, const uint8_t *bits);
 bool bp_layout_build(const Code &c, int L, BpLayout &out);
 void admm_layout_build(Code &c);
 
+// Static placement against LDS bank conflicts.  A wave64 LDS access is served in fixed lane groups and takes as many
+// LDS cycles as the busiest bank has distinct addresses (MI355X_MICROARCH.md, LDS).  Which group slot / variable cell a
+// lane touches in every instruction of the sweep is known when the decoder is created, so the two free permutations
+// (constraint group -> U slot, variable -> V cell) are chosen to spread every lane group over the banks:
+// items = groups or variables, position = slot or cell, a "set" = the items one lane group touches with one
+// instruction, bank class = position mod `modulus`.  Objective: sum over sets of sum over classes of count^2
+// (minimal when every class is hit at most once); deterministic simulated annealing over swaps of two positions.
+struct PlacementSet {
+    std::vector<int> items;
+    int modulus;
+};
+long placement_optimise(std::vector<int> &pos_of_item, int n_pos, const std::vector<PlacementSet> &sets, int rounds,
+                        std::vector<long> *per_set_max = nullptr);
+
 }  // namespace acg

@@ -271,7 +271,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f64" if a.algo == "qpadmm" else "f32"), "data": "synthetic",
         "config": {"workload": "%s: %s (%dx%d, E=%d) %s, %d iterations FIXED (no early exit), "
                                "%d AWGN frames per GPU per step at Es/N0 %.1f dB, inputs/outputs resident in HBM"
-                               % ("configs[4]" if a.synthetic else "configs[1]", os.path.basename(a.matrix), H.m, n, E,
+                               % ("configs[4]" if a.synthetic else ("configs[2]" if a.algo == "qpadmm" else "configs[1]"), os.path.basename(a.matrix), H.m, n, E,
                                   {"bp": "sum-product BP", "minsum": "min-sum(0.75) BP",
                                    "qpadmm": "QP-ADMM(%g,%g) fp64" % (a.alpha, a.mu)}[a.algo], a.iters, F, a.snr),
                    "engine": "streamed (messages in HBM)" if dec_fixed.layout(H)["lanes_per_frame"] == 1

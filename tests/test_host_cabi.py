@@ -108,3 +108,20 @@ def test_shard_ranges_partition():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == F
             for (lo, c), (lo2, _) in zip(spans, spans[1:]):
                 assert lo + c == lo2
+
+
+def test_lds_placement_optimiser(tmp_path):
+    """csrc/code.cpp placement_optimise (static placement of QP-ADMM groups / variables against LDS bank conflicts):
+    host-only; on a random gather pattern with the v-update's shape it must keep a permutation and cut the modelled
+    LDS cycles (sum over lane groups of the busiest bank) by at least a third."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "placement_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "placement_check.cpp"),
+                           os.path.join(root, "acg_alp_ldpc_amd", "csrc", "code.cpp"), "-o", exe])
+    out = subprocess.run([exe, "544", "300"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    before, after, nsets, _ms = out.stdout.split()
+    assert int(after) >= int(nsets)            # one cycle per lane group is the floor
+    assert int(after) <= 0.67 * int(before), out.stdout

@@ -51,7 +51,7 @@ if "FETCH_SIZE" in p and "WRITE_SIZE" in p and line:
     summary["traffic"] = {"frames": F, "iters": line["config"]["iters"],
                           "matrix": line["config"]["workload"].split(": ")[1].split(" ")[0],
                           "engine": "streamed" if line["config"]["layout"]["lanes_per_frame"] == 1 else "fused",
-                          "algo": "minsum" if "min-sum" in line["config"]["workload"] else "bp",
+                          "algo": "minsum" if "min-sum" in line["config"]["workload"] else ("qpadmm" if "QP-ADMM" in line["config"]["workload"] else "bp"),
                           "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                           "compulsory_input_bytes": F * n * 4, "kernel_ms": line["roofline"]["kernel_ms"],
                           "hbm_GBps_measured": (fetch + write) / (line["roofline"]["kernel_ms"] * 1e-3) / 1e9,
