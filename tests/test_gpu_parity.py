@@ -189,6 +189,35 @@ def test_qpadmm_guard_and_small_checks(A, oracle, matrices, pcm):
     assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
 
 
+def test_qpadmm_mixed_check_degrees_and_long_lists(A, oracle):
+    """workgroup-per-frame QP-ADMM beyond H05's shape: several passes and wavefronts, one- and two-variable checks
+    mixed with long ones (the GENERIC group instance next to the common one), variables in more checks than the
+    register-resident list holds (tail read from the table).  fp64: bits, flag and
+    sweep counts identical to the reference restatement (qp_admm.h:13-178)."""
+    rng = np.random.default_rng(11)
+    m, n = 230, 400
+    H = np.zeros((m, n), np.uint8)
+    degs = rng.choice([1, 2, 3, 4, 5, 6, 8], size=m, p=[0.08, 0.12, 0.2, 0.2, 0.2, 0.1, 0.1])
+    for i, d in enumerate(degs):
+        H[i, rng.choice(n, size=d, replace=False)] = 1
+    H[:9, 3] = 1                                                  # a variable in >= 9 checks (list longer than 6)
+    H[20:32, 5] = 1
+    for v in np.nonzero(H.sum(0) == 0)[0]:                        # an isolated variable has e = 0 and trips the guard
+        H[rng.integers(40, m), v] = 1                             # (qp_admm.h:108-114), tested elsewhere
+    cw = np.zeros((300, n), np.uint8)
+    y = (1.0 - 2.0 * cw) + 0.7 * rng.standard_normal((300, n))
+    ob, ook, oit = oracle.qpadmm_decode(H, y, 1.0, 0.6, 1.0, 60, 1e-6, threads=4)
+    for lpf in (0, 64):
+        dec = A.QPADMMDecoder(0.6, 1.0, 60, 1e-6, lanes_per_frame=lpf)
+        bits, ok, iters = dec.decode_batch(H, y, 1.0)
+        lay = dec.layout(H)
+        dec.close()
+        assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), (lpf, lay)
+        if lpf == 0:
+            assert lay["lanes_per_frame"] in (128, 192, 256), lay   # the workgroup-per-frame kernel took it
+    assert 1 < oit.mean() < 60                                      # the stopping rule was exercised both ways
+
+
 def test_qpadmm_fp32_fer_only(A, oracle, matrices, pcm):
     """fp32 QP-ADMM: FER-level agreement only (the 1/(mu*e-alpha)=20x gain amplifies rounding)"""
     from acg_alp_ldpc_amd import _lib
