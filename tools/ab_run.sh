@@ -17,5 +17,5 @@ for l in open("gpurun_out/ab_%s.log" % name):
 if not ok:
     print(name, open("gpurun_out/ab_%s.log" % name).read()[-800:])
 PY
-  timeout -k 10 200 python tools/mc_rate.py --algo qpadmm 2>&1 | grep "dB" | sed "s/^/  $name /"
+  timeout -k 10 200 python tools/mc_rate.py --algo qpadmm ${MC_ARGS} 2>&1 | grep "dB" | sed "s/^/  $name /"
 done
