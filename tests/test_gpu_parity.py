@@ -169,6 +169,24 @@ def test_qpadmm_vs_oracle_iters(A, oracle, matrices, pcm, lpf):
     assert dec.name() == "QP-ADMM"
 
 
+@pytest.mark.parametrize("name,alpha,mu", [("H05", 1.95, 0.5), ("optimalH", 1.2, 0.55)])
+def test_qpadmm_100k_frames_bits_and_sweep_counts(A, oracle, matrices, pcm, name, alpha, mu):
+    """the workgroup-per-frame kernel at volume: 100 000 frames over two SNRs, up to 200 sweeps, the reference's
+    parameters for each matrix (main.cpp:31,33) — fp64 hard decisions and the sweep at which the residual rule fires
+    (qp_admm.h:158-163) equal to the restatement on every frame"""
+    Hm, H = matrices[name], pcm[name]
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 23, 50000)
+    for snr, seed0 in ((-2.0, 500000), (1.0, 900000)):
+        y = oracle.transmit_frames(cws, snr, first_seed=seed0)
+        ob, ook, oit = oracle.qpadmm_decode(Hm, y, snr, alpha, mu, 200, 1e-5, threads=16)
+        dec = A.QPADMMDecoder(alpha, mu, 200, 1e-5)
+        bits, ok, iters = dec.decode_batch(H, y, snr)
+        dec.close()
+        assert (ok == ook).all() and (bits == ob).all(), (name, snr, int((bits != ob).any(axis=1).sum()))
+        assert (iters == oit).all(), (name, snr, int((iters != oit).sum()))
+
+
 def test_qpadmm_guard_and_small_checks(A, oracle, matrices, pcm):
     dec = A.QPADMMDecoder(2.0, 0.5, 10)          # e_min*mu = 2 <= alpha -> (zeros,false), qp_admm.h:112-114
     y = np.ones((5, pcm["H05"].n))
