@@ -69,7 +69,8 @@ typedef struct acg_ldpc_params {
                            frame, output LATCHED at the first zero syndrome (identical results). */
     int32_t precision;  /* ACG_LDPC_PREC_* */
     int32_t device;     /* HIP device ordinal; -1 = current device */
-    int32_t lanes_per_frame; /* 0 = auto; otherwise 16/32/64 lanes of a wavefront cooperate on one frame */
+    int32_t lanes_per_frame; /* 0 = auto; 16/32/64: that many lanes of a wavefront cooperate on one frame; 256 (BP also
+                                1024): one workgroup per frame (QP-ADMM then picks 128, 192 or 256 threads itself) */
     int32_t engine;     /* ACG_LDPC_ENGINE_* (BP only) */
     int32_t reserved;   /* must be 0 */
 } acg_ldpc_params;
