@@ -316,6 +316,31 @@ def main():
                            "mean_iters": q["mean_iters"], "snr_db": a.snr}
                 dms.close()
             out["minsum_0.75"] = ms
+            # configs[2]: QP-ADMM(alpha, mu) fp64, 100 sweeps, on the first quarter of the same frames (the run() helper
+            # decodes F frames, so the decoder is driven directly here); eps_stop 0 = every frame runs all sweeps
+            Fq = max(1, F // 4)
+            qa = {}
+            for eps, tag in ((0.0, "fixed"), (1e-5, "residual_exit")):
+                dq = A.QPADMMDecoder(a.alpha, a.mu, 100, eps, device=local_rank)
+                gen_noise(a.snr)
+                st = 3
+                for it_ in range(st + 1):
+                    if it_ == 1:
+                        barrier()
+                        t0 = time.perf_counter()
+                    dq.decode_batch_dev(H, y.data_ptr(), False, Fq, a.snr, bits.data_ptr(), okf.data_ptr(), its.data_ptr(),
+                                        stream.cuda_stream)
+                barrier()
+                dtq = time.perf_counter() - t0
+                if world > 1:
+                    tq = torch.tensor([dtq], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(tq, op=dist.ReduceOp.MAX)
+                    dtq = float(tq.item())
+                qa[tag] = {"value": world * Fq * st / dtq, "unit": "frames/s", "ms_per_step": dtq / st * 1e3,
+                           "frames_per_gpu": Fq, "mean_sweeps": float(its[:Fq].double().mean().item()), "snr_db": a.snr,
+                           "dtype": "f64", "layout": dq.layout(H)}
+                dq.close()
+            out["qpadmm_%g_%g_100" % (a.alpha, a.mu)] = qa
 
     # ---- CPU baseline (rank 0, N = 1 only) -------------------------------------------------------------
     if world == 1 and not a.no_cpu_baseline:
