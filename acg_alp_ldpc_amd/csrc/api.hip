@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <random>
@@ -29,7 +30,7 @@ hipError_t phi_debug_launch(const void *x, void *out, int n, int f64, hipStream_
 hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t first_frame, uint64_t seed,
                        const uint32_t *cw_packed, int64_t n_cw, float sigma, hipStream_t s);
 
-const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds);
+const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, bool idxreg);
 const void *bp_streamed_ptr(int algo, int f64);
 hipError_t bp_streamed_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid,
                               int block, hipStream_t s);
@@ -385,7 +386,9 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
         d->lds_block = per_frame + t.idx_lds_bytes;
         const int algo_b = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
         for (int mc = 0; mc < 2; mc++) {
-            const void *kp = bp_block_kernel_ptr(algo_b, d->f64, L, mc != 0, idxlds);
+            // index table too large for LDS and variable degree <= 4: keep it in registers (decode kernel only)
+            const bool idxreg = !idxlds && c.max_vdeg <= 4 && lay.n_vpass <= 12 && getenv("ACG_BP_NO_IDXREG") == nullptr;
+            const void *kp = bp_block_kernel_ptr(algo_b, d->f64, L, mc != 0, idxlds, idxreg);
             if (!kp) {
                 set_error("no workgroup-per-frame kernel instance for this configuration");
                 return 3;

@@ -9,7 +9,8 @@
 namespace acg {
 #include "bp_core.inc"
 
-template <typename T, int L, int ALGO, bool MC, bool IDXLDS>
+// IDXREG: the variable-side index table in registers (variable degree <= 4, table too large for LDS): see var_phase_regs
+template <typename T, int L, int ALGO, bool MC, bool IDXLDS, bool IDXREG = false>
 __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int MAXD = 8;
@@ -29,11 +30,13 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
     Core core(t, A, A, OB, IDX, l, a.ms_scale);
     typename Core::LlrRegs lr;
     typename Core::VarIds vi;
+    typename Core::IdxRegs ir;
 #pragma unroll
     for (int p = 0; p < NVP; ++p) {
         lr[p] = (T) 0;
         vi[p] = (p < t.n_vpass) ? t.v_var[p * L + l] : -1;
     }
+    if (IDXREG) core.load_idx_regs(ir);
     unsigned long long acc_correct = 0, acc_pseudo = 0, acc_total = 0, acc_ham = 0, acc_ham_ok = 0, acc_ham_wrong = 0, acc_iters = 0;
     // padding words and the zero cell are +0.0 for the whole launch
     for (int w = l; w < t.a_words; w += L) A[w] = (T) 0;
@@ -101,15 +104,25 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
         // ---- sweeps (bp.h:186-197) -----------------------------------------------------------------------------
         int it = 0;
         bool latched = false;
+        uint32_t hard = IDXREG ? core.llr_hard_mask(lr) : 0u;  // IDXREG: hard decisions of my variables, bit per pass
         for (;;) {
-            const bool bad = __syncthreads_or(core.syndrome_bad() ? 1 : 0) != 0;
+            bool bad;
+            if (IDXREG) {
+                // the check sweep reads every v->c word anyway: it also delivers the syndrome of the hard bits riding in
+                // them (no separate syndrome pass, one barrier less per sweep).  Its c->v output is wasted on the last trip.
+                bad = __syncthreads_or(core.check_phase_syndrome(true) ? 1 : 0) != 0;
+            } else {
+                bad = __syncthreads_or(core.syndrome_bad() ? 1 : 0) != 0;
+            }
             const bool conv = it > 0 && it <= a.max_iter && !bad;  // bp.h:195 (max_iter = 0: never)
             const bool out_now = conv && !latched;
             const bool finish = (a.early_exit && conv) || it >= a.max_iter;
             const bool fail_now = finish && !conv && !latched;
             if (out_now || fail_now) {  // block-uniform
-                if (out_now) core.pack_bits(lr, vi);
-                else {
+                if (out_now) {
+                    if (IDXREG) core.pack_bits_mask(hard, vi);
+                    else core.pack_bits(lr, vi);
+                } else {
                     for (int w = l; w < t.nwords; w += L) OB[w] = 0u;  // bp.h:198
                     __syncthreads();
                 }
@@ -138,9 +151,13 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                 latched = true;
             }
             if (finish) break;
-            core.check_phase(true);
-            __syncthreads();
-            core.var_phase(lr, true);
+            if (IDXREG) {
+                hard = core.var_phase_regs(lr, ir, true);
+            } else {
+                core.check_phase(true);
+                __syncthreads();
+                core.var_phase(lr, true);
+            }
             __syncthreads();
             it += 1;
         }
@@ -169,8 +186,25 @@ static const void *blk_ptr_l(int L, bool mc, bool idxlds) {
     return nullptr;
 }
 
-// workgroup-per-frame kernels exist for node degree <= 8, L in {256, 1024}
-const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds) {
+template <typename T, int ALGO>
+static const void *blk_ptr_idxreg(int L) {
+    if (L == 256) return (const void *) bp_block_kernel<T, 256, ALGO, false, false, true>;
+    if (L == 1024) return (const void *) bp_block_kernel<T, 1024, ALGO, false, false, true>;
+    return nullptr;
+}
+
+// workgroup-per-frame kernels exist for node degree <= 8, L in {256, 1024}; idxreg (decode only, no LDS index copy):
+// the index table lives in registers
+const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, bool idxreg) {
+    if (idxreg && !mc && !idxlds) {
+#ifdef ACG_FAST_BUILD
+        if (f64 || algo) return nullptr;
+        return blk_ptr_idxreg<float, 0>(L);
+#else
+        if (algo == 0) return f64 ? blk_ptr_idxreg<double, 0>(L) : blk_ptr_idxreg<float, 0>(L);
+        return f64 ? blk_ptr_idxreg<double, 1>(L) : blk_ptr_idxreg<float, 1>(L);
+#endif
+    }
 #ifdef ACG_FAST_BUILD
     if (f64 || algo) return nullptr;
     return blk_ptr_l<float, 0>(L, mc, idxlds);
