@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -191,6 +192,26 @@ bool bp_layout_build(const Code &c, int L, BpLayout &o) {
     auto vdeg = [&](int j) { return c.col_ptr[j + 1] - c.col_ptr[j]; };
     std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return cdeg(a) > cdeg(b); });
     std::stable_sort(vorder.begin(), vorder.end(), [&](int a, int b) { return vdeg(a) > vdeg(b); });
+    // The word of edge (check, j) lives at pass offset + j*L + lane of the check, i.e. in LDS bank (lane mod 32) when L is
+    // a multiple of 32; the variable sweep gathers and scatters those words 32 lanes at a time.  Checks and variables
+    // of equal degree are interchangeable in the order above, so for the workgroup-per-frame kernels (where the LDS
+    // array is the busiest unit and more than half of its cycles were bank conflicts) they are placed to spread every
+    // such access over the banks (placement_optimise_gather).  Message values do not depend on the placement.
+    if (L >= 256 && c.E > 0 && getenv("ACG_BP_NO_PLACEMENT") == nullptr) {
+        std::vector<int> clabel(m), vlabel(n);
+        for (int i = 0; i < m; i++) clabel[i] = cdeg(i);
+        for (int j = 0; j < n; j++) vlabel[j] = vdeg(j);
+        std::vector<std::vector<int>> chk_of_var(n);
+        for (int j = 0; j < n; j++)
+            for (int k = 0; k < vdeg(j); k++) {
+                const int e = c.col_edge[c.col_ptr[j] + k];  // edge ids are check-major: find the check by its row range
+                chk_of_var[j].push_back((int) (std::upper_bound(c.row_ptr.begin(), c.row_ptr.end(), e) - c.row_ptr.begin()) - 1);
+            }
+        long before = 0, after = 0;
+        placement_optimise_gather(corder, clabel, vorder, vlabel, chk_of_var, 32, 32, c.E > 20000 ? 150 : 600, &before, &after);
+        if (getenv("ACG_BP_PLACEMENT_DEBUG"))
+            fprintf(stderr, "[acg_ldpc] BP placement L=%d: modelled LDS cycles of the variable-sweep gathers %ld -> %ld\n", L, before, after);
+    }
 
     o.n_cpass = (m + L - 1) / L;
     o.n_vpass = (n + L - 1) / L;
@@ -382,5 +403,123 @@ long placement_optimise(std::vector<int> &pos_of_item, const int n_pos, const st
     return total;
 }
 
+
+// Joint placement for a gather (the variable sweep of the fused BP kernels): reader r at position s (lane s % lanes of
+// lane group s / lanes) touches, in step k, the item items_of_reader[r][k]; the bank class of an item is its slot mod
+// `modulus`.  Two kinds of move, both keeping the degree-sorted order the kernels rely on: two items with the same label
+// swap slots, or two readers with the same label swap positions.  Same objective (sum of squared bank multiplicities)
+// and annealing schedule as placement_optimise; deterministic.
+long placement_optimise_gather(std::vector<int> &item_at_slot, const std::vector<int> &item_label, std::vector<int> &reader_at_pos,
+                               const std::vector<int> &reader_label, const std::vector<std::vector<int>> &items_of_reader,
+                               const int lanes, const int modulus, const int rounds, long *cycles_before, long *cycles_after) {
+    const int n_items = (int) item_at_slot.size(), n_readers = (int) reader_at_pos.size();
+    size_t kmax = 0;
+    for (const auto &v : items_of_reader) kmax = std::max(kmax, v.size());
+    if (cycles_before) *cycles_before = 0;
+    if (cycles_after) *cycles_after = 0;
+    if (n_readers == 0 || n_items == 0 || kmax == 0) return 0;
+    const int n_lane_groups = (n_readers + lanes - 1) / lanes;
+    std::vector<int> cnt((size_t) n_lane_groups * kmax * modulus, 0);
+    auto cell = [&](int pos, int k, int slot) -> int & { return cnt[((size_t) (pos / lanes) * kmax + k) * modulus + slot % modulus]; };
+    std::vector<int> pos_of_reader(n_readers, -1), slot_of_item(n_items, -1);
+    for (int s = 0; s < n_readers; s++) pos_of_reader[reader_at_pos[s]] = s;
+    for (int s = 0; s < n_items; s++) slot_of_item[item_at_slot[s]] = s;
+    std::vector<std::vector<std::pair<int, int>>> uses(n_items);  // item -> (reader, k)
+    long total = 0;
+    for (int s = 0; s < n_readers; s++) {
+        const int r = reader_at_pos[s];
+        for (size_t k = 0; k < items_of_reader[r].size(); k++) {
+            const int it = items_of_reader[r][k];
+            uses[it].push_back({r, (int) k});
+            int &cc = cell(s, (int) k, slot_of_item[it]);
+            total += 2 * cc + 1;
+            cc++;
+        }
+    }
+    auto add = [&](int pos, int k, int slot, int sign) {
+        int &cc = cell(pos, k, slot);
+        if (sign > 0) {
+            total += 2 * cc + 1;
+            cc++;
+        } else {
+            total -= 2 * cc - 1;
+            cc--;
+        }
+    };
+    auto cycles = [&]() {
+        long cyc = 0;
+        for (size_t base = 0; base < cnt.size(); base += modulus) cyc += *std::max_element(cnt.begin() + base, cnt.begin() + base + modulus);
+        return cyc;
+    };
+    if (cycles_before) *cycles_before = cycles();
+    auto move_item = [&](int it, int newslot) {
+        if (slot_of_item[it] % modulus != newslot % modulus)
+            for (const auto &u : uses[it]) {
+                add(pos_of_reader[u.first], u.second, slot_of_item[it], -1);
+                add(pos_of_reader[u.first], u.second, newslot, +1);
+            }
+        slot_of_item[it] = newslot;
+    };
+    auto move_reader = [&](int r, int newpos) {
+        if (pos_of_reader[r] / lanes != newpos / lanes)
+            for (size_t k = 0; k < items_of_reader[r].size(); k++) {
+                add(pos_of_reader[r], (int) k, slot_of_item[items_of_reader[r][k]], -1);
+                add(newpos, (int) k, slot_of_item[items_of_reader[r][k]], +1);
+            }
+        pos_of_reader[r] = newpos;
+    };
+    uint64_t rng = 0xD1B54A32D192ED03ull;
+    auto next = [&]() {
+        rng ^= rng << 13;
+        rng ^= rng >> 7;
+        rng ^= rng << 17;
+        return rng;
+    };
+    const long moves = (long) rounds * (n_items + n_readers);
+    for (long mv = 0; mv < moves; mv++) {
+        const double T = 1.5 * std::pow(0.05 / 1.5, (double) mv / (double) moves);
+        const long before = total;
+        const bool item_move = (next() & 1) != 0;
+        int a, b, sa, sb;
+        if (item_move) {
+            sa = (int) (next() % (uint64_t) n_items);
+            sb = (int) (next() % (uint64_t) n_items);
+            a = item_at_slot[sa];
+            b = item_at_slot[sb];
+            if (sa == sb || item_label[a] != item_label[b] || sa % modulus == sb % modulus) continue;
+            move_item(a, sb);
+            move_item(b, sa);
+        } else {
+            sa = (int) (next() % (uint64_t) n_readers);
+            sb = (int) (next() % (uint64_t) n_readers);
+            a = reader_at_pos[sa];
+            b = reader_at_pos[sb];
+            if (sa == sb || reader_label[a] != reader_label[b] || sa / lanes == sb / lanes) continue;
+            move_reader(a, sb);
+            move_reader(b, sa);
+        }
+        const long delta = total - before;
+        const bool reject = delta > 0 && (double) (next() >> 11) * (1.0 / 9007199254740992.0) >= std::exp(-(double) delta / T);
+        if (item_move) {
+            if (reject) {
+                move_item(b, sb);
+                move_item(a, sa);
+            } else {
+                item_at_slot[sb] = a;
+                item_at_slot[sa] = b;
+            }
+        } else {
+            if (reject) {
+                move_reader(b, sb);
+                move_reader(a, sa);
+            } else {
+                reader_at_pos[sb] = a;
+                reader_at_pos[sa] = b;
+            }
+        }
+    }
+    if (cycles_after) *cycles_after = cycles();
+    return total;
+}
 
 }  // namespace acg

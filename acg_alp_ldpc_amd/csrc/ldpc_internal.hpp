@@ -84,4 +84,8 @@ struct PlacementSet {
 long placement_optimise(std::vector<int> &pos_of_item, int n_pos, const std::vector<PlacementSet> &sets, int rounds,
                         std::vector<long> *per_set_max = nullptr);
 
+long placement_optimise_gather(std::vector<int> &item_at_slot, const std::vector<int> &item_label, std::vector<int> &reader_at_pos,
+                               const std::vector<int> &reader_label, const std::vector<std::vector<int>> &items_of_reader, int lanes,
+                               int modulus, int rounds, long *cycles_before = nullptr, long *cycles_after = nullptr);
+
 }  // namespace acg

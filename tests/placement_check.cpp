@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <string>
 
 #include "../acg_alp_ldpc_amd/csrc/ldpc_internal.hpp"
 
@@ -11,7 +12,41 @@ namespace acg {
 void set_error(const std::string &) {}  // code.cpp reports through the library's error slot (api.hip)
 }
 
+// "gather" mode: acg::placement_optimise_gather on a random (3,6)-regular structure (readers = variables, items = checks)
+static int gather_mode(int n_checks) {
+    const int n_vars = 2 * n_checks;
+    uint64_t rng = 777;
+    auto next = [&]() {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        return (uint32_t) (rng >> 33);
+    };
+    std::vector<int> sockets;
+    for (int c = 0; c < n_checks; c++)
+        for (int j = 0; j < 6; j++) sockets.push_back(c);
+    for (int i = (int) sockets.size() - 1; i > 0; i--) std::swap(sockets[i], sockets[next() % (uint32_t) (i + 1)]);
+    std::vector<std::vector<int>> chk_of_var(n_vars);
+    for (int v = 0; v < n_vars; v++)
+        for (int k = 0; k < 3; k++) chk_of_var[v].push_back(sockets[3 * v + k]);
+    std::vector<int> corder(n_checks), vorder(n_vars), clabel(n_checks), vlabel(n_vars, 3);
+    std::iota(corder.begin(), corder.end(), 0);
+    std::iota(vorder.begin(), vorder.end(), 0);
+    for (int c = 0; c < n_checks; c++) clabel[c] = c < n_checks / 2 ? 6 : 7;  // two label classes: swaps must stay inside a class
+    long before = 0, after = 0;
+    acg::placement_optimise_gather(corder, clabel, vorder, vlabel, chk_of_var, 32, 32, 200, &before, &after);
+    std::vector<int> seen(n_checks, 0);
+    for (int s = 0; s < n_checks; s++) {
+        if (corder[s] < 0 || corder[s] >= n_checks || seen[corder[s]]++) return printf("NOT A PERMUTATION\n"), 1;
+        if (clabel[corder[s]] != (s < n_checks / 2 ? 6 : 7)) return printf("LABEL ORDER BROKEN\n"), 1;
+    }
+    std::vector<int> seenv(n_vars, 0);
+    for (int s = 0; s < n_vars; s++)
+        if (vorder[s] < 0 || vorder[s] >= n_vars || seenv[vorder[s]]++) return printf("NOT A PERMUTATION\n"), 1;
+    printf("%ld %ld %d 0\n", before, after, 3 * ((n_vars + 31) / 32));
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 3 && std::string(argv[3]) == "gather") return gather_mode(atoi(argv[1]));
     const int n_items = argc > 1 ? atoi(argv[1]) : 544, rounds = argc > 2 ? atoi(argv[2]) : 2000;
     std::vector<acg::PlacementSet> sets;
     uint64_t rng = 12345;

@@ -125,3 +125,8 @@ def test_lds_placement_optimiser(tmp_path):
     before, after, nsets, _ms = out.stdout.split()
     assert int(after) >= int(nsets)            # one cycle per lane group is the floor
     assert int(after) <= 0.67 * int(before), out.stdout
+    # the joint (items + readers, label-preserving) variant used for the BP variable sweep
+    out = subprocess.run([exe, "600", "0", "gather"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    before, after, nsets, _ = out.stdout.split()
+    assert int(nsets) <= int(after) <= 0.75 * int(before), out.stdout
