@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    if "bp_fused" not in k and "admm" not in k: continue
+    if "bp_" not in k and "admm" not in k: continue
     for c, v in d.items():
         print(k, c, "n=%d mean=%.6g" % (len(v), sum(v) / len(v)))
 PY
