@@ -446,6 +446,43 @@ def test_config5_synthetic_regular_code(A, oracle):
     assert r.sum_hamming == r.sum_hamming_ok + r.sum_hamming_wrong
 
 
+def test_config5_block_kernel_variants_agree_near_threshold(A, oracle):
+    """The workgroup-per-frame instance used for the (3,6) 5000 x 10000 code (index table in registers, syndrome taken
+    from the check sweep, bank-conflict placement) against the plain instance (ACG_BP_NO_IDXREG / ACG_BP_NO_PLACEMENT)
+    and the HBM-streamed engine, at an SNR where frames exit anywhere between 10 sweeps and never: the three share the
+    arithmetic, so bits, flags and exit iterations must be identical; a few frames also against the oracle."""
+    Hm = A.regular_ldpc(5000, 10000, 3, 6, seed=1)
+    H = A.ParityCheckMatrix(Hm)
+    rng = np.random.default_rng(7)
+    snr = -1.75        # Es/N0; the (3,6) threshold is about -1.9 dB
+    sigma = np.sqrt(A.llr_variance(snr))
+    y = 1.0 + sigma * rng.standard_normal((192, 10000))
+    for make in (lambda **kw: A.BeliefPropagationDecoder(60, **kw), lambda **kw: A.MinSumDecoder(60, 0.75, **kw)):
+        dec = make()
+        assert dec.layout(H)["lanes_per_frame"] == 1024
+        b0, k0, i0 = dec.decode_batch(H, y, snr)
+        dec.close()
+        assert 0 < k0.sum() and len(set(i0[k0 == 1].tolist())) > 3      # a spread of exit iterations
+        os.environ["ACG_BP_NO_IDXREG"] = "1"
+        os.environ["ACG_BP_NO_PLACEMENT"] = "1"
+        try:
+            dec = make()
+            b1, k1, i1 = dec.decode_batch(H, y, snr)
+            dec.close()
+        finally:
+            del os.environ["ACG_BP_NO_IDXREG"], os.environ["ACG_BP_NO_PLACEMENT"]
+        assert (k0 == k1).all() and (b0 == b1).all() and (i0 == i1).all()
+        dec = make(engine=A.ENGINE_STREAMED)
+        b2, k2, i2 = dec.decode_batch(H, y, snr)
+        dec.close()
+        assert (k0 == k2).all() and (b0 == b2).all() and (i0 == i2).all()
+    ob, ook, oit = oracle.bp_decode(Hm, y[:8], snr, 60, threads=8)
+    dec = A.BeliefPropagationDecoder(60)
+    bits, ok, iters = dec.decode_batch(H, y[:8], snr)
+    dec.close()
+    assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+
+
 @pytest.mark.parametrize("name", MATS)
 @pytest.mark.parametrize("snr", [-2.0, 2.0])
 def test_bp_soft_messages_vs_reference_trace(A, pcm, name, snr):
