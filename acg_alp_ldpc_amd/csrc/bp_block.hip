@@ -104,10 +104,13 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
         // ---- sweeps (bp.h:186-197) -----------------------------------------------------------------------------
         int it = 0;
         bool latched = false;
-        uint32_t hard = IDXREG ? core.llr_hard_mask(lr) : 0u;  // IDXREG: hard decisions of my variables, bit per pass
+        // decode instances (MERGED): the syndrome comes out of the check sweep and the hard decisions of my variables live
+        // in a register bit mask (bit per pass); the Monte-Carlo instances keep the separate syndrome pass
+        constexpr bool MERGED = !MC;
+        uint32_t hard = MERGED ? core.llr_hard_mask(lr) : 0u;
         for (;;) {
             bool bad;
-            if (IDXREG) {
+            if (MERGED) {
                 // the check sweep reads every v->c word anyway: it also delivers the syndrome of the hard bits riding in
                 // them (no separate syndrome pass, one barrier less per sweep).  Its c->v output is wasted on the last trip.
                 bad = __syncthreads_or(core.check_phase_syndrome(true) ? 1 : 0) != 0;
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
             const bool fail_now = finish && !conv && !latched;
             if (out_now || fail_now) {  // block-uniform
                 if (out_now) {
-                    if (IDXREG) core.pack_bits_mask(hard, vi);
+                    if (MERGED) core.pack_bits_mask(hard, vi);
                     else core.pack_bits(lr, vi);
                 } else {
                     for (int w = l; w < t.nwords; w += L) OB[w] = 0u;  // bp.h:198
@@ -151,8 +154,8 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                 latched = true;
             }
             if (finish) break;
-            if (IDXREG) {
-                hard = core.var_phase_regs(lr, ir, true);
+            if (MERGED) {
+                hard = IDXREG ? core.var_phase_regs(lr, ir, true) : core.var_phase_hard(lr, true);
             } else {
                 core.check_phase(true);
                 __syncthreads();
