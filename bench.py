@@ -261,8 +261,12 @@ def main():
                 nv, nt = pm["SQ_INSTS_VALU"], pm.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
                 clk = pm["GRBM_GUI_ACTIVE"] / 8 / (pj["kernel_stats"][0]["avg_ms"] * 1e-3)
                 busy = ((nv - nt) * 2 + nt * 12) / 1024
-                valu = {"issue_cycles_per_simd_per_launch": busy, "shader_clock_hz": clk,
-                        "frac_of_valu_issue_capacity": busy / (clk * kms * 1e-3), "source": "profiles/" + pf}
+                valu = {"shader_clock_hz": clk, "source": "profiles/" + pf}
+                if a.algo != "qpadmm":  # fp64 VALU ops issue at 4 cycles: the 2/12-cycle pricing only fits the fp32 kernels
+                    valu.update({"issue_cycles_per_simd_per_launch": busy, "frac_of_valu_issue_capacity": busy / (clk * kms * 1e-3)})
+                if "SQ_LDS_IDX_ACTIVE" in pm:  # LDS-array cycles (incl. bank conflicts) summed over the 256 CUs
+                    valu["frac_of_lds_array_cycles"] = pm["SQ_LDS_IDX_ACTIVE"] / 256 / (clk * kms * 1e-3)
+                    valu["lds_bank_conflict_share"] = pm.get("SQ_LDS_BANK_CONFLICT", 0.0) / pm["SQ_LDS_IDX_ACTIVE"]
     except Exception:
         valu = None
     out = {
