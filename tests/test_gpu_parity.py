@@ -205,6 +205,15 @@ def test_qpadmm_guard_and_small_checks(A, oracle, matrices, pcm):
     dec = A.QPADMMDecoder(0.6, 1.0, 80, 1e-6)
     bits, ok, iters = dec.decode_batch(H, y, 1.0)
     assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
+    # a sweep budget of 1 (budget 0 is not mirrored: the reference then returns its dead-store initial guess
+    # v = (q > 0), qp_admm.h:116-119, i.e. the complement of the channel hard decision; the kernels return zeros)
+    for budget in (1,):
+        ob, ook, oit = oracle.qpadmm_decode(H, y, 1.0, 0.6, 1.0, budget, 1e-6, threads=2)
+        for lpf in (0, 64):
+            dec = A.QPADMMDecoder(0.6, 1.0, budget, 1e-6, lanes_per_frame=lpf)
+            bits, ok, iters = dec.decode_batch(H, y, 1.0)
+            dec.close()
+            assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), (budget, lpf)
 
 
 def test_qpadmm_mixed_check_degrees_and_long_lists(A, oracle):
