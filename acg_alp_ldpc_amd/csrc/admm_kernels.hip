@@ -471,6 +471,9 @@ constexpr int ADMM_VK = 6;  // list entries per variable slot kept in registers 
 #ifndef ADMM_OCC
 #define ADMM_OCC 8  // launch bound: ADMM_OCC - BP workgroups of 4 wavefronts per CU
 #endif
+#ifndef ADMM_OCC_F32
+#define ADMM_OCC_F32 2  // extra workgroups per CU asked of the fp32 instances (fewer registers, half the LDS): measured best
+#endif
 
 template <typename T> struct AdmmVec;
 template <> struct AdmmVec<double> {
@@ -583,7 +586,7 @@ __device__ __forceinline__ void admm_group_update(unsigned char *smem, const uin
 // BP = passes (of blockDim.x constraint groups / variables) the register-resident structure is sized for; fewer passes
 // = fewer registers = more wavefronts per SIMD (launch bound: 4, 5, 6 workgroups of 4 wavefronts per CU for BP = 4, 3, 2).
 template <typename T, bool EE, int BP>
-__global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP) admm_block_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
+__global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? ADMM_OCC_F32 : 0)) admm_block_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
                                                               const T mu, const T eps_stop) {
     using X = AdmmVec<T>;
     extern __shared__ __attribute__((aligned(32))) unsigned char smem[];
