@@ -857,7 +857,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
             const size_t ts_ = (p.precision == ACG_LDPC_PREC_F32) ? 4 : 8;
             const size_t lds = (size_t) (4 * gp * cand + A.n_var + 4) * ts_ + 64;
             const int by_lds = (int) ((160 * 1024) / lds);
-            const int by_reg = ((8 - passes) * 4) / (cand / 64);
+            const int by_reg = ((ADMM_OCC - passes + (ts_ == 4 ? ADMM_OCC_F32 : 0)) * 4) / (cand / 64);
             double score = (double) std::min(by_lds, by_reg) / passes;
             if (force && atoi(force) == cand) score = 1e9;
             if (score > best_score) {
