@@ -187,6 +187,29 @@ def test_qpadmm_100k_frames_bits_and_sweep_counts(A, oracle, matrices, pcm, name
         assert (iters == oit).all(), (name, snr, int((iters != oit).sum()))
 
 
+@pytest.mark.parametrize("force_l", [128, 192, 256])
+def test_qpadmm_workgroup_sizes_and_pass_instances(A, oracle, matrices, pcm, force_l):
+    """the three workgroup sizes of the workgroup-per-frame QP-ADMM kernel (and with them its 2-, 3- and 4-pass
+    instances: H.txt needs 2-4 passes, H05 3-4) give the reference's bits and sweep counts"""
+    os.environ["ACG_ADMM_BLOCK_L"] = str(force_l)
+    try:
+        for name, alpha, mu in (("H", 1.9, 0.5), ("H05", 1.95, 0.5)):
+            Hm, H = matrices[name], pcm[name]
+            G, _ = oracle.get_orthogonal(Hm)
+            cws = oracle.gen_codewords(G, 77, 1500)
+            y = oracle.transmit_frames(cws, -1.5, first_seed=4242)
+            ob, ook, oit = oracle.qpadmm_decode(Hm, y, -1.5, alpha, mu, 150, 1e-5, threads=8)
+            dec = A.QPADMMDecoder(alpha, mu, 150, 1e-5)
+            bits, ok, iters = dec.decode_batch(H, y, -1.5)
+            lay = dec.layout(H)
+            dec.close()
+            assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all(), (name, lay)
+            if name == "H05" and force_l != 128:     # 541 group slots need 5 passes of 128: that size is skipped
+                assert lay["lanes_per_frame"] == force_l, lay
+    finally:
+        del os.environ["ACG_ADMM_BLOCK_L"]
+
+
 def test_qpadmm_guard_and_small_checks(A, oracle, matrices, pcm):
     dec = A.QPADMMDecoder(2.0, 0.5, 10)          # e_min*mu = 2 <= alpha -> (zeros,false), qp_admm.h:112-114
     y = np.ones((5, pcm["H05"].n))
