@@ -117,6 +117,7 @@ struct AdmmDevice {
     const void *kernel[2] = {nullptr, nullptr};
     size_t lds_block = 0;
     bool guard = false;  // e_min*mu <= alpha  (qp_admm.h:108-114)
+    bool budget0 = false;  // max_iter == 0: handled by admm_budget0_kernel
     double alpha = 0, mu = 0, eps = 0;
 };
 
@@ -777,6 +778,30 @@ __global__ void admm_guard_kernel(DecodeArgs a, int nwords) {
     }
 }
 
+// sweep budget 0: the loop of qp_admm.h:130 never runs, so the word returned (qp_admm.h:166-175) is the initial guess
+// v_i = (q_i > 0) of qp_admm.h:116-119 — a dead store for every other budget.  ok = true, no sweeps.  Dispatched by the
+// host (max_iter is launch-uniform); the sweep kernels never see max_iter == 0.
+template <typename T>
+__global__ void admm_budget0_kernel(DecodeArgs a, int n, int nwords) {
+    const int64_t total = a.frames * nwords;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t f = i / nwords;
+        const int w = (int) (i - f * nwords);
+        uint32_t word = 0;
+        for (int b = 0; b < 32 && w * 32 + b < n; ++b) {
+            const size_t idx = (size_t) f * n + (size_t) (w * 32 + b);
+            const double yv = a.y_is_f64 ? reinterpret_cast<const double *>(a.y)[idx] : (double) reinterpret_cast<const float *>(a.y)[idx];
+            const T q = (T) (2 * yv / a.var);  // CalculateCoef, algo/algo.h:13-20 (same expression as the sweep kernels)
+            word |= (q > (T) 0 ? 1u : 0u) << b;
+        }
+        if (a.out_bits) a.out_bits[i] = word;
+        if (w == 0) {
+            if (a.out_ok) a.out_ok[f] = 1;  // qp_admm.h:165,177
+            if (a.out_iters) a.out_iters[f] = 0;
+        }
+    }
+}
+
 constexpr int ADMM_NGP = 12;  // register-resident row state for codes with <= 12*64 constraint groups
 
 template <typename T, int L, int NGP>
@@ -882,6 +907,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     double e_min = 1e9;
     for (double e : A.e) e_min = std::min(e_min, e);
     d->guard = (e_min * p.mu <= p.alpha);
+    d->budget0 = (p.max_iter == 0);
 
     AdmmDevTables &t = d->t;
     t.n = c.n;
@@ -1183,7 +1209,7 @@ void admm_device_destroy(AdmmDevice *d) {
 bool admm_device_unfused_mc(const AdmmDevice *d, const int32_t **row_ptr, const int32_t **edge_var) {
     if (row_ptr) *row_ptr = d->t.row_ptr;
     if (edge_var) *edge_var = d->t.edge_var;
-    return d->blockmode && !d->guard;
+    return (d->blockmode || d->budget0) && !d->guard;
 }
 
 void admm_device_layout(const AdmmDevice *d, int *lds_per_frame, int *lanes, int *frames_per_block, int *grid) {
@@ -1212,6 +1238,17 @@ hipError_t admm_launch(AdmmDevice *d, const DecodeArgs &a, hipStream_t s, std::s
         }
         int grid = (int) std::min<int64_t>((a.frames + 255) / 256, 4096);
         hipLaunchKernelGGL(admm_guard_kernel, dim3(grid), dim3(256), 0, s, a, d->t.nwords);
+        return hipGetLastError();
+    }
+    if (a.max_iter == 0) {
+        if (a.mc) {
+            err = "internal: QP-ADMM with a sweep budget of 0 has no fused Monte-Carlo mode";
+            return hipErrorInvalidValue;
+        }
+        const int64_t total = a.frames * d->t.nwords;
+        int grid = (int) std::min<int64_t>((total + 255) / 256, 8192);
+        if (d->f32) hipLaunchKernelGGL(admm_budget0_kernel<float>, dim3(grid), dim3(256), 0, s, a, d->t.n, d->t.nwords);
+        else hipLaunchKernelGGL(admm_budget0_kernel<double>, dim3(grid), dim3(256), 0, s, a, d->t.n, d->t.nwords);
         return hipGetLastError();
     }
     if (d->blockmode && a.mc) {

@@ -31,6 +31,8 @@ hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t firs
                        const uint32_t *cw_packed, int64_t n_cw, float sigma, hipStream_t s);
 
 const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, bool idxreg);
+const void *bp_kernel_ptr_dbg(int f64, int L);
+const void *bp_block_kernel_ptr_dbg(int f64);
 const void *bp_streamed_ptr(int algo, int f64);
 hipError_t bp_streamed_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid,
                               int block, hipStream_t s);
@@ -90,6 +92,8 @@ struct acg_ldpc_decoder {
     int grid_cap[2] = {0, 0};          // [mc] resident blocks: occupancy x CUs
     const void *kernel[2] = {nullptr, nullptr};
     size_t lds_block = 0;
+    int variant = -1;       // wave-group kernels: 0 / 1 / 2 (see bp_inst_*.hip); -1 = workgroup-per-frame
+    bool blk_idxlds = false, blk_idxreg = false;
     // streamed BP engine
     bool streamed = false;
     StreamTables stab{};
@@ -112,6 +116,17 @@ struct acg_ldpc_decoder {
     int64_t cw_count = 0;
     uint64_t cw_hash = 0;
     unsigned long long *counters = nullptr;
+    // Per-launch work counters: every launch takes the next slot of a small ring of device words (the dynamic frame /
+    // tile hand-out of the kernels), so launches of one handle that overlap on different streams never share one.
+    // ring_ev[k] is recorded behind the launch that used slot k; the next user of the slot — and, for the streamed
+    // engine, whose HBM slabs belong to the handle, every launch on a different stream — waits on it on the device.
+    static constexpr int WORK_RING = 32;
+    unsigned long long *work_ring = nullptr;
+    hipEvent_t ring_ev[WORK_RING] = {};
+    bool ring_used[WORK_RING] = {};
+    uint64_t launch_seq = 0;
+    int last_slot = -1;
+    hipStream_t last_stream = nullptr;
 };
 
 extern "C" {
@@ -389,6 +404,10 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
             // index table too large for LDS and variable degree <= 4: keep it in registers (decode kernel only)
             const bool idxreg = !idxlds && c.max_vdeg <= 4 && lay.n_vpass <= 12 && getenv("ACG_BP_NO_IDXREG") == nullptr;
             const void *kp = bp_block_kernel_ptr(algo_b, d->f64, L, mc != 0, idxlds, idxreg);
+            if (mc == 0) {
+                d->blk_idxlds = idxlds;
+                d->blk_idxreg = idxreg;
+            }
             if (!kp) {
                 set_error("no workgroup-per-frame kernel instance for this configuration");
                 return 3;
@@ -422,6 +441,7 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
     for (int mc = 0; mc < 2; mc++) {
         const int variant = idxlds ? ((llr_regs) ? 2 : 1) : 0;
+        d->variant = variant;
         const void *kp = bp_kernel_ptr(algo, d->f64, d->maxd, L, mc != 0, variant);
         if (!kp) {
             set_error("no kernel instance for this configuration");
@@ -473,7 +493,14 @@ int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *pa
         d->cu_count = prop.multiProcessorCount;
         if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = 10; break; }
         if (hipEventCreate(&d->ev0) != hipSuccess || hipEventCreate(&d->ev1) != hipSuccess) { set_error("hipEventCreate failed"); rc = 10; break; }
-        if (hipMalloc((void **) &d->counters, sizeof(unsigned long long) * (MC_NCOUNTERS + 1)) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
+        if (hipMalloc((void **) &d->counters, sizeof(unsigned long long) * MC_NCOUNTERS) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
+        if (hipMalloc((void **) &d->work_ring, sizeof(unsigned long long) * acg_ldpc_decoder::WORK_RING) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
+        {
+            bool evok = true;
+            for (int k = 0; k < acg_ldpc_decoder::WORK_RING; k++)
+                evok = evok && hipEventCreateWithFlags(&d->ring_ev[k], hipEventDisableTiming) == hipSuccess;
+            if (!evok) { set_error("hipEventCreate failed"); rc = 10; break; }
+        }
         if (params->algo == ACG_LDPC_QPADMM) {
             d->name = "QP-ADMM";  // qp_admm.h:189
             std::string err;
@@ -509,6 +536,9 @@ void acg_ldpc_decoder_destroy(acg_ldpc_decoder *d) {
     if (d->st_iters) (void) hipFree(d->st_iters);
     if (d->cw_dev) (void) hipFree(d->cw_dev);
     if (d->counters) (void) hipFree(d->counters);
+    if (d->work_ring) (void) hipFree(d->work_ring);
+    for (int k = 0; k < acg_ldpc_decoder::WORK_RING; k++)
+        if (d->ring_ev[k]) (void) hipEventDestroy(d->ring_ev[k]);
     if (d->ev0) (void) hipEventDestroy(d->ev0);
     if (d->ev1) (void) hipEventDestroy(d->ev1);
     if (d->stream) (void) hipStreamDestroy(d->stream);
@@ -536,17 +566,21 @@ static void fill_channel(DecodeArgs &a, double snr) {
     a.sigma = (float) std::sqrt(var);
 }
 
-// launch on stream s (events recorded around the kernel on that stream)
+// launch on stream s (events recorded around the kernel on that stream).  Caller holds d->mu.
 static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
     a.max_iter = d->p.max_iter;
     a.early_exit = d->p.early_exit;
     a.ms_scale = (float) d->p.ms_scale;
     if (a.frames <= 0) return 0;
+    // this launch's own work counter (see acg_ldpc_decoder::work_ring)
+    const int slot = (int) (d->launch_seq++ % acg_ldpc_decoder::WORK_RING);
+    if (d->ring_used[slot]) HIP_OK(hipStreamWaitEvent(s, d->ring_ev[slot], 0));
+    if (d->streamed && d->last_slot >= 0 && d->last_stream != s) HIP_OK(hipStreamWaitEvent(s, d->ring_ev[d->last_slot], 0));
+    a.work_counter = d->work_ring + slot;
+    HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
     HIP_OK(hipEventRecord(d->ev0, s));
     if (d->admm) {
         std::string err;
-        a.work_counter = d->counters + MC_NCOUNTERS;
-        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
         hipError_t e = admm_launch(d->admm, a, s, err);
         if (e != hipSuccess) {
             set_error(err.empty() ? std::string("admm launch: ") + hipGetErrorString(e) : err);
@@ -563,19 +597,18 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         while (W < 8 && tiles * W < 8 * (int64_t) d->cu_count) W <<= 1;
         const int per_cu = (W <= 4) ? 2 : 1;
         int grid = (int) std::min<int64_t>(tiles, (int64_t) per_cu * d->cu_count);
-        a.work_counter = d->counters + MC_NCOUNTERS;
-        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
         HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
     } else {
         int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
         const int mc = a.mc ? 1 : 0;
-        // dynamic frame hand-out: counters[MC_NCOUNTERS] is the work counter of this launch
-        a.work_counter = d->counters + MC_NCOUNTERS;
-        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
         int grid = (int) std::min<int64_t>(blocks, d->grid_cap[mc]);
         HIP_OK(bp_launch(d->kernel[mc], d->tab, a, grid, d->block, d->lds_block, s));
     }
     HIP_OK(hipEventRecord(d->ev1, s));
+    HIP_OK(hipEventRecord(d->ring_ev[slot], s));
+    d->ring_used[slot] = true;
+    d->last_slot = slot;
+    d->last_stream = s;
     d->ev_valid = true;
     return 0;
 }
@@ -942,27 +975,46 @@ int acg_ldpc_transmit_host(const uint8_t *codewords, int64_t n_codewords, int32_
 
 // ---------------------------------------------------------------- debug helpers (tests only)
 int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t frames, double snr, int32_t iters,
-                            int32_t f64, double *c2v, double *v2c_mag, double *v2c_sgn, double *post) {
+                            int32_t f64, int32_t engine, int32_t lanes_per_frame, double *c2v, double *v2c_mag,
+                            double *v2c_sgn, double *post) {
     if (!code || !y || frames < 1 || frames > 64 || iters < 1) {
         set_error("bad argument (1..64 frames, iters >= 1)");
         return 1;
     }
+    const bool fused = (engine == ACG_LDPC_ENGINE_FUSED);
     acg_ldpc_params p;
     acg_ldpc_params_default(&p);
     p.algo = ACG_LDPC_BP_SUMPRODUCT;
     p.max_iter = iters;
     p.early_exit = 0;
-    p.engine = ACG_LDPC_ENGINE_STREAMED;
+    p.engine = fused ? ACG_LDPC_ENGINE_FUSED : ACG_LDPC_ENGINE_STREAMED;
+    p.lanes_per_frame = fused ? lanes_per_frame : 0;
     p.precision = f64 ? ACG_LDPC_PREC_F64 : ACG_LDPC_PREC_DEFAULT;
     acg_ldpc_decoder *d = nullptr;
     if (int rc = acg_ldpc_decoder_create(code, &p, &d)) return rc;
     const int n = d->c.n, E = d->c.E;
     const size_t ts = f64 ? 8 : 4;
+    // words per frame of the three dumps: streamed [E][64] / [E][64] / [n][64]; fused [frame][a_words] x2 / [frame][n_vpass*L]
+    size_t wc = (size_t) E * 64, wp = (size_t) n * 64;
+    if (fused) {
+        const void *kp = nullptr;
+        if (d->variant == 2 && d->maxd <= 8) kp = bp_kernel_ptr_dbg(f64, d->L);
+        else if (d->variant == -1 && d->L == 256 && d->blk_idxlds && !d->blk_idxreg) kp = bp_block_kernel_ptr_dbg(f64);
+        if (!kp) {
+            set_error("no debug instance of the fused kernel for this code / lanes_per_frame");
+            acg_ldpc_decoder_destroy(d);
+            return 3;
+        }
+        if (d->lds_block > 64 * 1024) (void) hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block);
+        d->kernel[0] = kp;
+        wc = (size_t) frames * d->tab.a_words;
+        wp = (size_t) frames * d->lay.n_vpass * d->L;
+    }
     void *dc = nullptr, *dv = nullptr, *dp = nullptr;
     int rc = 0;
     do {
-        if (hipMalloc(&dc, (size_t) E * 64 * ts) != hipSuccess || hipMalloc(&dv, (size_t) E * 64 * ts) != hipSuccess ||
-            hipMalloc(&dp, (size_t) n * 64 * ts) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
+        if (hipMalloc(&dc, wc * ts) != hipSuccess || hipMalloc(&dv, wc * ts) != hipSuccess ||
+            hipMalloc(&dp, wp * ts) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
         if ((rc = ensure_staging(d, frames))) break;
         if (hipMemcpy(d->st_y, y, (size_t) frames * n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = 10; break; }
         DecodeArgs a{};
@@ -978,7 +1030,7 @@ int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t 
         a.dbg_post = dp;
         if ((rc = launch_decode(d, a, d->stream))) break;
         if (hipStreamSynchronize(d->stream) != hipSuccess) { set_error("sync failed"); rc = 10; break; }
-        std::vector<unsigned char> hc((size_t) E * 64 * ts), hv((size_t) E * 64 * ts), hp((size_t) n * 64 * ts);
+        std::vector<unsigned char> hc(wc * ts), hv(wc * ts), hp(wp * ts);
         (void) hipMemcpy(hc.data(), dc, hc.size(), hipMemcpyDeviceToHost);
         (void) hipMemcpy(hv.data(), dv, hv.size(), hipMemcpyDeviceToHost);
         (void) hipMemcpy(hp.data(), dp, hp.size(), hipMemcpyDeviceToHost);
@@ -988,24 +1040,52 @@ int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t 
             if (f64) return reinterpret_cast<const double *>(b.data())[idx];
             return unscale * (double) reinterpret_cast<const float *>(b.data())[idx];
         };
-        for (int f = 0; f < frames; f++) {
-            for (int e = 0; e < E; e++) {  // edge order: check-major, variables ascending (same as the oracle's trace)
-                c2v[(size_t) f * E + e] = get(hc, (size_t) e * 64 + f);
-                // a v->c word = magnitude | hard-decision bit in the LSB | sign: strip the LSB before reading it
+        // a v->c word = magnitude | hard-decision bit in the LSB | sign: strip the LSB before reading it
+        auto get_v2c = [&](size_t idx) -> double {
+            if (f64) {
+                uint64_t u = reinterpret_cast<const uint64_t *>(hv.data())[idx] & ~1ull;
                 double w;
-                if (f64) {
-                    uint64_t u = reinterpret_cast<const uint64_t *>(hv.data())[(size_t) e * 64 + f] & ~1ull;
-                    std::memcpy(&w, &u, 8);
-                } else {
-                    uint32_t u = reinterpret_cast<const uint32_t *>(hv.data())[(size_t) e * 64 + f] & ~1u;
-                    float wf;
-                    std::memcpy(&wf, &u, 4);
-                    w = unscale * (double) wf;
-                }
+                std::memcpy(&w, &u, 8);
+                return w;
+            }
+            uint32_t u = reinterpret_cast<const uint32_t *>(hv.data())[idx] & ~1u;
+            float wf;
+            std::memcpy(&wf, &u, 4);
+            return unscale * (double) wf;
+        };
+        // where edge e (check-major, variables ascending — the oracle's trace order) and variable v live in the dumps
+        std::vector<size_t> epos((size_t) E), vslot((size_t) n, (size_t) -1);
+        if (fused) {
+            const BpLayout &lay = d->lay;
+            for (int sl = 0; sl < lay.n_cpass * lay.L; sl++) {
+                const int chk = lay.c_chk[sl];
+                if (chk < 0) continue;
+                const int pss = sl / lay.L, l = sl % lay.L;
+                for (int j = 0; j < d->c.row_ptr[chk + 1] - d->c.row_ptr[chk]; j++)
+                    epos[(size_t) d->c.row_ptr[chk] + j] = (size_t) lay.c_off[pss] + (size_t) j * lay.L + l;
+            }
+            for (int sl = 0; sl < lay.n_vpass * lay.L; sl++)
+                if (lay.v_var[sl] >= 0) vslot[lay.v_var[sl]] = (size_t) sl;
+        }
+        for (int f = 0; f < frames; f++) {
+            auto eidx = [&](int e) { return fused ? (size_t) f * d->tab.a_words + epos[e] : (size_t) e * 64 + f; };
+            for (int e = 0; e < E; e++) {
+                c2v[(size_t) f * E + e] = get(hc, eidx(e));
+                const double w = get_v2c(eidx(e));
                 v2c_mag[(size_t) f * E + e] = std::fabs(w);
                 v2c_sgn[(size_t) f * E + e] = std::signbit(w) ? -1.0 : 1.0;
             }
-            for (int v = 0; v < n; v++) post[(size_t) f * n + v] = get(hp, (size_t) v * 64 + f);
+            for (int v = 0; v < n; v++) {
+                if (!fused) {
+                    post[(size_t) f * n + v] = get(hp, (size_t) v * 64 + f);
+                    continue;
+                }
+                // estimate() = llr + sum of the c->v mailbox (bp.h:85-90), summed here from the kernel's own c->v words
+                // and channel LLR (slot order dump), checks ascending
+                double sum = 0;
+                for (int k = d->c.col_ptr[v]; k < d->c.col_ptr[v + 1]; k++) sum += c2v[(size_t) f * E + d->c.col_edge[k]];
+                post[(size_t) f * n + v] = get(hp, (size_t) f * d->lay.n_vpass * d->L + vslot[v]) + sum;
+            }
         }
     } while (0);
     if (dc) (void) hipFree(dc);

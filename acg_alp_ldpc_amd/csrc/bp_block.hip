@@ -10,7 +10,8 @@ namespace acg {
 #include "bp_core.inc"
 
 // IDXREG: the variable-side index table in registers (variable degree <= 4, table too large for LDS): see var_phase_regs
-template <typename T, int L, int ALGO, bool MC, bool IDXLDS, bool IDXREG = false>
+// DBG: tests only, see bp_fused_kernel
+template <typename T, int L, int ALGO, bool MC, bool IDXLDS, bool IDXREG = false, bool DBG = false>
 __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int MAXD = 8;
@@ -154,6 +155,9 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                 latched = true;
             }
             if (finish) break;
+            if (DBG && MERGED && it == a.max_iter - 1 && a.dbg_c2v)  // (the barrier inside __syncthreads_or ordered the sweep)
+                for (int w = l; w < t.a_words; w += L) reinterpret_cast<T *>(a.dbg_c2v)[(size_t) frame * t.a_words + w] = A[w];
+            if (DBG) __syncthreads();
             if (MERGED) {
                 hard = IDXREG ? core.var_phase_regs(lr, ir, true) : core.var_phase_hard(lr, true);
             } else {
@@ -162,6 +166,12 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                 core.var_phase(lr, true);
             }
             __syncthreads();
+            if (DBG && it == a.max_iter - 1 && a.dbg_v2c) {
+                for (int w = l; w < t.a_words; w += L) reinterpret_cast<T *>(a.dbg_v2c)[(size_t) frame * t.a_words + w] = A[w];
+                for (int p = 0; p < t.n_vpass; ++p)
+                    reinterpret_cast<T *>(a.dbg_post)[(size_t) frame * (t.n_vpass * L) + p * L + l] = core.get_llr(lr, p, p * L + l);
+                __syncthreads();
+            }
             it += 1;
         }
     }
@@ -194,6 +204,16 @@ static const void *blk_ptr_idxreg(int L) {
     if (L == 256) return (const void *) bp_block_kernel<T, 256, ALGO, false, false, true>;
     if (L == 1024) return (const void *) bp_block_kernel<T, 1024, ALGO, false, false, true>;
     return nullptr;
+}
+
+// tests only (acg_ldpc_debug_bp_trace): 256 threads per frame, index table in LDS, message dump compiled in
+const void *bp_block_kernel_ptr_dbg(int f64) {
+#ifdef ACG_FAST_BUILD
+    if (f64) return nullptr;
+#else
+    if (f64) return (const void *) bp_block_kernel<double, 256, 0, false, true, false, true>;
+#endif
+    return (const void *) bp_block_kernel<float, 256, 0, false, true, false, true>;
 }
 
 // workgroup-per-frame kernels exist for node degree <= 8, L in {256, 1024}; idxreg (decode only, no LDS index copy):

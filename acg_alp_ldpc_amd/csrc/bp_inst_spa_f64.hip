@@ -41,4 +41,12 @@ const void *bp_kernel_ptr_spa_f64(int maxd, int L, bool mc, int variant) {
     return nullptr;
 }
 
+// tests only (acg_ldpc_debug_bp_trace): the headline instance (degree <= 8, index table in LDS, LLRs in registers) with
+// the message dump compiled in
+const void *bp_kernel_ptr_spa_f64_dbg(int L) {
+    if (L == 64) return (const void *) bp_fused_kernel<double, 8, 64, 0, false, true, BP_NVP, true>;
+    if (L == 32) return (const void *) bp_fused_kernel<double, 8, 32, 0, false, true, BP_NVP, true>;
+    return nullptr;
+}
+
 }  // namespace acg

@@ -38,6 +38,16 @@ const void *bp_kernel_ptr_spa_f64(int maxd, int L, bool mc, int variant);
 const void *bp_kernel_ptr_ms_f32(int maxd, int L, bool mc, int variant);
 const void *bp_kernel_ptr_ms_f64(int maxd, int L, bool mc, int variant);
 
+const void *bp_kernel_ptr_spa_f32_dbg(int L);
+const void *bp_kernel_ptr_spa_f64_dbg(int L);
+const void *bp_kernel_ptr_dbg(int f64, int L) {
+#ifdef ACG_FAST_BUILD
+    return f64 ? nullptr : bp_kernel_ptr_spa_f32_dbg(L);
+#else
+    return f64 ? bp_kernel_ptr_spa_f64_dbg(L) : bp_kernel_ptr_spa_f32_dbg(L);
+#endif
+}
+
 // algo: 0 sum-product, 1 min-sum; f64: 0/1
 const void *bp_kernel_ptr(int algo, int f64, int maxd, int L, bool mc, int variant) {
 #ifdef ACG_FAST_BUILD

@@ -11,10 +11,15 @@
  * no torch / STL types.  Every entry point cites the reference interface it replaces.
  * INTEGRATION.md shows the binding a reference maintainer would add.
  *
- * Threading: a decoder handle owns one HIP stream + workspace on one device; calls on the same
+ * Threading: a decoder handle owns one HIP stream + workspace on one device; host calls on the same
  * handle are serialised by an internal mutex (the reference calls one decoder object from
  * THREADS_NUM pthreads, experiment.h:101,127-130 — that keeps working, one handle per thread
  * is faster).  Code handles are immutable after creation and may be shared.
+ * Streams: acg_ldpc_decode_batch_dev is asynchronous on the caller's stream.  Launches of ONE handle on
+ * DIFFERENT streams may overlap on the device: each launch owns its work counter (a ring of 32 per handle,
+ * a slot is reused only behind the launch that held it).  The streamed BP engine keeps its message slabs
+ * in the handle, so its launches are ordered on the device (a launch on another stream waits for the
+ * previous one through an event) — correct, not concurrent; use one handle per stream to overlap those.
  */
 #ifndef ACG_LDPC_H
 #define ACG_LDPC_H
@@ -130,7 +135,8 @@ int acg_ldpc_decode_batch(acg_ldpc_decoder *dec, const double *y, int64_t frames
  *   y_dev        device, frames*n of float (y_is_f64=0) or double (y_is_f64=1)
  *   bits_dev     device, frames*words uint32, words = (n+31)/32; bit v of a frame = word v>>5, bit v&31
  *   ok_dev       device, frames bytes;  iters_dev device, frames int32 (may be NULL)
- *   stream       hipStream_t to launch on (NULL = the decoder's own stream); asynchronous. */
+ *   stream       hipStream_t to launch on (NULL = the decoder's own stream); asynchronous.  The output buffers of
+ *                two launches in flight must not overlap; see "Streams" at the top of this file. */
 int acg_ldpc_decode_batch_dev(acg_ldpc_decoder *dec, const void *y_dev, int32_t y_is_f64, int64_t frames,
                               double snr, uint32_t *bits_dev, uint8_t *ok_dev, int32_t *iters_dev, void *stream);
 /* block until the decoder's own stream is idle */
@@ -193,9 +199,14 @@ int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f6
 /* diagnostics: soft state of the device sum-product decoder after `iters` full iterations of bp.h:183-199 without
  * the exit test, for 1..64 frames (y: frames*n doubles).  Outputs are frames*E (edge order: check-major, variables
  * ascending) / frames*n doubles: c2v = messages check->variable, (v2c_mag, v2c_sgn) = the (phi(|x|), sign) pairs
- * variable->check, post = VNode::estimate() (bp.h:85-90).  Runs on the streamed engine. */
+ * variable->check, post = VNode::estimate() (bp.h:85-90).
+ * engine: ACG_LDPC_ENGINE_STREAMED (or AUTO) = the HBM engine; ACG_LDPC_ENGINE_FUSED = the LDS-resident kernels, read out
+ * of LDS by a debug instance of the same kernel: lanes_per_frame 0/32/64 = wavefront groups (node degree <= 8, n <= 12
+ * passes), 256 = one workgroup per frame (index table in LDS).  For the fused kernels `post` is the channel LLR plus the
+ * sum of the dumped c2v words, added on the host. */
 int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t frames, double snr, int32_t iters,
-                            int32_t f64, double *c2v, double *v2c_mag, double *v2c_sgn, double *post);
+                            int32_t f64, int32_t engine, int32_t lanes_per_frame, double *c2v, double *v2c_mag,
+                            double *v2c_sgn, double *post);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,8 @@
 // Micro-benchmark (developer tool, not part of the product): VALU issue rates on gfx950 that the BP
 // kernel's cost model depends on.  hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
 //   1. v_fma_f32 throughput per SIMD at 1..8 waves/SIMD
-//   2. v_exp_f32 / v_log_f32 throughput
+//   2. v_exp_f32 / v_log_f32 throughput: "exp"/"log" time the pair mul+exp / add+log, "exp-alone"/"log-alone" the
+//      transcendental by itself (its price = the pair minus one 2-cycle op if the two do not overlap)
 //   3. does a wave64 VALU op with one 32-lane half fully EXEC-masked issue in half the time?
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,6 +27,14 @@ __global__ void k(float *out, int mask_upper) {
 #undef F
             } else if (MODE == 2) {
 #define F(x) x = __builtin_amdgcn_logf(x + 2.0f)
+                F(a0); F(a1); F(a2); F(a3); F(a4); F(a5); F(a6); F(a7);
+#undef F
+            } else if (MODE == 4) {  // v_exp_f32 ALONE (negation is a free source modifier; the value settles at the fixed point 0.641...)
+#define F(x) x = __builtin_amdgcn_exp2f(-x)
+                F(a0); F(a1); F(a2); F(a3); F(a4); F(a5); F(a6); F(a7);
+#undef F
+            } else if (MODE == 5) {  // v_log_f32 ALONE (|x| is a free source modifier)
+#define F(x) x = __builtin_amdgcn_logf(__builtin_fabsf(x))
                 F(a0); F(a1); F(a2); F(a3); F(a4); F(a5); F(a6); F(a7);
 #undef F
             } else {  // dependent chain
@@ -63,6 +72,8 @@ int main() {
     for (int w : {1, 2, 4, 8}) run<0>("fma", w, 0, d);
     for (int w : {1, 2, 4, 8}) run<1>("exp", w, 0, d);
     for (int w : {1, 4, 8}) run<2>("log", w, 0, d);
+    for (int w : {1, 2, 4, 8}) run<4>("exp-alone", w, 0, d);
+    for (int w : {1, 4, 8}) run<5>("log-alone", w, 0, d);
     for (int w : {1, 2, 4, 8}) run<3>("fma-chain", w, 0, d);
     for (int w : {1, 4, 8}) run<0>("fma", w, 1, d);
     for (int w : {4}) run<1>("exp", w, 1, d);
