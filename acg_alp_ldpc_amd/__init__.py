@@ -11,7 +11,7 @@ from .code import ParityCheckMatrix  # noqa: F401
 from .codes import regular_ldpc  # noqa: F401
 from .decoder import BeliefPropagationDecoder, Decoder, MinSumDecoder, QPADMMDecoder  # noqa: F401
 from .experiment import (ExperimentResult, merge_exp_results, run_experiment,  # noqa: F401
-                         run_experiment_sharded, shard_range)
+                         run_experiment_inproc, run_experiment_sharded, shard_range)
 
 
 def read_pcm(path):

@@ -522,4 +522,526 @@ long placement_optimise_gather(std::vector<int> &item_at_slot, const std::vector
     return total;
 }
 
+
+// ---------------------------------------------------------------- quasi-cyclic structure
+bool code_detect_qc(const Code &c, QcInfo &q) {
+    const int g0 = std::gcd(c.m, c.n);
+    for (int Z = g0; Z >= 2; --Z) {
+        if (g0 % Z) continue;
+        const int mb = c.m / Z, nb = c.n / Z;
+        std::vector<int> shift((size_t) mb * nb, -1), ones((size_t) mb * nb, 0);
+        bool ok = true;
+        for (int r = 0; r < c.m && ok; r++) {
+            const int R = r / Z, k = r % Z;
+            int lastC = -1;
+            for (int e = c.row_ptr[r]; e < c.row_ptr[r + 1] && ok; e++) {
+                const int v = c.edge_var[e], C = v / Z, l = v % Z;
+                const int sft = (l - k + Z) % Z;  // optimize_H.cpp:41
+                int &cur = shift[(size_t) R * nb + C];
+                if (C == lastC || (cur >= 0 && cur != sft)) ok = false;  // two ones of a row in one block / not a shift
+                cur = sft;
+                ones[(size_t) R * nb + C]++;
+                lastC = C;
+            }
+        }
+        for (size_t b = 0; b < ones.size() && ok; b++) ok = (ones[b] == 0 || ones[b] == Z);
+        if (ok) {
+            q.Z = Z;
+            q.mb = mb;
+            q.nb = nb;
+            q.shift = shift;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- QP-ADMM block-kernel placement
+namespace {
+
+int admm_llen(const AdmmLayout &A, int i) { return A.var_ptr[i + 1] - A.var_ptr[i]; }
+
+// members of group g in ASCENDING variable id (the order of the row phase of admm_block_kernel)
+int admm_members(const AdmmLayout &A, int g, int out[3]) {
+    const int ty = A.grp_type[g];
+    for (int k = 0; k < ty; k++) out[k] = A.grp_var[(size_t) g * 3 + k];
+    std::sort(out, out + ty);
+    return ty;
+}
+
+// modelled LDS cycles of one frame-sweep for a given placement
+void admm_model_cycles(const Code &c, AdmmBlockPlacement &P, bool f32) {
+    const AdmmLayout &A = c.admm;
+    const int L = P.L;
+    P.cyc_u_reads = P.cyc_v_reads = P.cyc_v_writes = 0;
+    P.ideal_u_reads = P.ideal_v_reads = P.ideal_v_writes = 0;
+    for (int w = 0; w < 4; w++) P.wave_cost[w] = 0;
+    std::vector<int> seen;  // distinct addresses per bank
+    auto cycles_of = [&](std::vector<int> &addrs, int modulus) {  // addrs: word-granular addresses, -1 = lane inactive
+        std::sort(addrs.begin(), addrs.end());
+        addrs.erase(std::unique(addrs.begin(), addrs.end()), addrs.end());
+        seen.assign(modulus, 0);
+        int mx = 0;
+        for (int a : addrs)
+            if (a >= 0) mx = std::max(mx, ++seen[a % modulus]);
+        return mx;
+    };
+    // v-update: lanes [32h, 32h+32) of (pass, wavefront) read entry k < ml(pass, wavefront) of their variables
+    for (int p = 0; p < P.n_vpass; p++)
+        for (int w = 0; w < L / 64 + (L % 64 ? 1 : 0); w++) {
+            int ml = 0;
+            for (int l = 64 * w; l < std::min(L, 64 * w + 64); l++) {
+                const int i = P.var_of_slot[(size_t) p * L + l];
+                if (i >= 0) ml = std::max(ml, admm_llen(A, i));
+            }
+            if (w < 4) P.wave_cost[w] += ml;
+            for (int h = 0; h < 2; h++)
+                for (int k = 0; k < ml; k++) {
+                    std::vector<int> addrs;
+                    for (int l = 64 * w + 32 * h; l < std::min(L, 64 * w + 32 * h + 32); l++) {
+                        const int i = P.var_of_slot[(size_t) p * L + l];
+                        if (i >= 0 && k < admm_llen(A, i)) addrs.push_back(P.slot_of_grp[A.var_grp[A.var_ptr[i] + k] >> 2]);
+                        else addrs.push_back(P.zero_gslot);  // padding entries read the all-zero slot
+                    }
+                    if (addrs.empty()) continue;
+                    P.cyc_u_reads += cycles_of(addrs, 32);
+                    P.ideal_u_reads += 1;
+                }
+        }
+    // row phase: lanes of a 32-slot service group read member k of their groups (predicated off for empty slots)
+    std::vector<int> grp_of((size_t) P.n_gpass * L, -1);
+    for (int g = 0; g < A.n_grp; g++) grp_of[P.slot_of_grp[g]] = g;
+    for (int base = 0; base < P.n_gpass * L; base += 32)
+        for (int k = 0; k < 3; k++) {
+            std::vector<int> addrs;
+            for (int sl = base; sl < base + 32; sl++) {
+                const int g = grp_of[sl];
+                if (g < 0) continue;
+                int mem[3];
+                const int ty = admm_members(A, g, mem);
+                addrs.push_back(k < ty ? P.cell_of_var[mem[k]] : P.zero_cell);
+            }
+            if (addrs.empty()) continue;
+            P.cyc_v_reads += cycles_of(addrs, 32);
+            P.ideal_v_reads += 1;
+        }
+    // v-update stores: ds_write_b64 is served 16 lanes at a time (16 bank pairs), ds_write_b32 32 lanes at a time
+    const int wl = f32 ? 32 : 16;
+    for (int base = 0; base < P.n_vpass * L; base += wl) {
+        std::vector<int> addrs;
+        for (int s = base; s < base + wl; s++)
+            if (P.var_of_slot[s] >= 0) addrs.push_back(P.cell_of_var[P.var_of_slot[s]]);
+        if (addrs.empty()) continue;
+        P.cyc_v_writes += cycles_of(addrs, wl);
+        P.ideal_v_writes += 1;
+    }
+}
+
+// ---- mode 1: list-length order + simulated annealing of the two address maps (any code) ----------------------------
+void admm_placement_annealed(const Code &c, AdmmBlockPlacement &P, bool f32, bool tune) {
+    const AdmmLayout &A = c.admm;
+    const int L = P.L;
+    // variables sorted by list length (descending) so a pass has a uniform trip count
+    std::vector<int> vorder(A.n_var);
+    std::iota(vorder.begin(), vorder.end(), 0);
+    std::stable_sort(vorder.begin(), vorder.end(), [&](int x, int y) { return admm_llen(A, x) > admm_llen(A, y); });
+    P.var_of_slot.assign((size_t) P.n_vpass * L, -1);
+    for (int s = 0; s < A.n_var; s++) P.var_of_slot[s] = vorder[s];
+    // slots: three-variable checks first, then the one- and two-variable ones (their wavefronts run the GENERIC
+    // instance of admm_group_update), then padding; slot n_grp is the all-zero slot list padding points to
+    P.slot_of_grp.assign(A.n_grp, 0);
+    {
+        int sl = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int g = 0; g < A.n_grp; g++)
+                if ((A.grp_type[g] == 3) == (pass == 0)) P.slot_of_grp[g] = sl++;
+            if (pass == 0) P.n3 = sl;
+        }
+    }
+    P.zero_gslot = A.n_grp;
+    P.zero_cell = A.n_var;
+    P.n_cells = A.n_var + 1;
+    P.cell_of_var.resize(A.n_var);
+    std::iota(P.cell_of_var.begin(), P.cell_of_var.end(), 0);
+    if (tune && P.n3 > 1) {
+        // v-update: lanes [32h, 32h+32) of (pass, wavefront) read entry k of their variables: bank = slot mod 32
+        std::vector<int> item_of_grp(A.n_grp, -1), pos3;
+        for (int g = 0; g < A.n_grp; g++)
+            if (A.grp_type[g] == 3) {
+                item_of_grp[g] = (int) pos3.size();
+                pos3.push_back(P.slot_of_grp[g]);
+            }
+        std::vector<PlacementSet> sets;
+        for (int p_ = 0; p_ < P.n_vpass; p_++) {
+            const int maxlist = admm_llen(A, vorder[(size_t) p_ * L]);
+            for (int h = 0; h < L / 32; h++)
+                for (int k = 0; k < maxlist; k++) {
+                    PlacementSet ps;
+                    ps.modulus = 32;
+                    for (int l = 32 * h; l < 32 * h + 32; l++) {
+                        const int sidx = p_ * L + l;
+                        if (sidx >= A.n_var) continue;
+                        const int i = vorder[sidx];
+                        if (k >= admm_llen(A, i)) continue;
+                        const int g = A.var_grp[A.var_ptr[i] + k] >> 2;
+                        if (item_of_grp[g] >= 0) ps.items.push_back(item_of_grp[g]);
+                    }
+                    if (ps.items.size() > 1) sets.push_back(std::move(ps));
+                }
+        }
+        placement_optimise(pos3, P.n3, sets, 800);
+        for (int g = 0; g < A.n_grp; g++)
+            if (item_of_grp[g] >= 0) P.slot_of_grp[g] = pos3[item_of_grp[g]];
+    }
+    if (tune && A.n_var > 1) {
+        std::vector<int> grp_of((size_t) P.n_gpass * L, -1);
+        for (int g = 0; g < A.n_grp; g++) grp_of[P.slot_of_grp[g]] = g;
+        std::vector<PlacementSet> sets;
+        // row phase: lanes [32h, 32h+32) of a group pass read member k of their groups: bank = cell mod 32
+        for (int base = 0; base < P.n_gpass * L; base += 32)
+            for (int k = 0; k < 3; k++) {
+                PlacementSet ps;
+                ps.modulus = 32;
+                for (int sl = base; sl < base + 32; sl++) {
+                    const int g = grp_of[sl];
+                    if (g < 0) continue;
+                    int mem[3];
+                    if (k < admm_members(A, g, mem)) ps.items.push_back(mem[k]);
+                }
+                if (ps.items.size() > 1) sets.push_back(std::move(ps));
+            }
+        const int wl = f32 ? 32 : 16;
+        for (int base = 0; base < A.n_var; base += wl) {
+            PlacementSet ps;
+            ps.modulus = wl;
+            for (int sidx = base; sidx < std::min(base + wl, A.n_var); sidx++) ps.items.push_back(vorder[sidx]);
+            if (ps.items.size() > 1) sets.push_back(std::move(ps));
+        }
+        placement_optimise(P.cell_of_var, A.n_var, sets, 800);
+    }
+}
+
+// ---- mode 2: tuples of a quasi-cyclic code ---------------------------------------------------------------------------
+struct TupleSide {
+    int n_items = 0;
+    std::vector<std::vector<int>> refs;  // refs[item][k] = item of the OTHER side read by entry k
+    std::vector<int> label;              // items may only trade places with items of the same label
+    std::vector<int> pos;                // tuple position
+    std::vector<std::vector<std::pair<int, int>>> readers;  // (item of the other side, k) that read this item
+};
+
+// Joint search over the tuple positions of both sides.  Position = svc * M + cls: a service group holds M tuples, the
+// class of a tuple is its position inside the service group.  Energy = sum over (side, service group, k) of the squared
+// class multiplicities of the tuples read — minimal (= number of reads) iff every service group reads M distinct classes.
+// cost_unit: positions [u*cost_unit, (u+1)*cost_unit) form a wavefront pass whose v-update cost is its largest label;
+// a move into an empty position is allowed only where it does not raise that maximum (side 0 only).
+long tuple_joint_placement(TupleSide (&S)[2], const int n_pos, const int M, const int cost_unit, const int rounds) {
+    std::vector<int> at[2];
+    size_t kmax[2] = {0, 0};
+    for (int s = 0; s < 2; s++) {
+        at[s].assign(n_pos, -1);
+        for (int i = 0; i < S[s].n_items; i++) {
+            at[s][S[s].pos[i]] = i;
+            kmax[s] = std::max(kmax[s], S[s].refs[i].size());
+        }
+        S[s].readers.assign(S[s].n_items, {});
+    }
+    for (int s = 0; s < 2; s++)
+        for (int i = 0; i < S[s].n_items; i++)
+            for (size_t k = 0; k < S[s].refs[i].size(); k++) S[1 - s].readers[S[s].refs[i][k]].push_back({i, (int) k});
+    const int n_svc = (n_pos + M - 1) / M;
+    std::vector<int> cnt[2];
+    long total = 0;
+    auto cell = [&](int s, int svc, int k, int cls) -> int & { return cnt[s][((size_t) svc * kmax[s] + k) * M + cls]; };
+    auto add = [&](int s, int svc, int k, int cls, int sign) {
+        int &cc = cell(s, svc, k, cls);
+        if (sign > 0) {
+            total += 2 * cc + 1;
+            cc++;
+        } else {
+            total -= 2 * cc - 1;
+            cc--;
+        }
+    };
+    for (int s = 0; s < 2; s++) {
+        cnt[s].assign((size_t) n_svc * std::max<size_t>(kmax[s], 1) * M, 0);
+        for (int i = 0; i < S[s].n_items; i++)
+            for (size_t k = 0; k < S[s].refs[i].size(); k++) add(s, S[s].pos[i] / M, (int) k, S[1 - s].pos[S[s].refs[i][k]] % M, +1);
+    }
+    auto move = [&](int s, int x, int np) {
+        const int op = S[s].pos[x];
+        if (op / M != np / M)  // as a reader: its entries change service group
+            for (size_t k = 0; k < S[s].refs[x].size(); k++) {
+                const int cls = S[1 - s].pos[S[s].refs[x][k]] % M;
+                add(s, op / M, (int) k, cls, -1);
+                add(s, np / M, (int) k, cls, +1);
+            }
+        if (op % M != np % M)  // as a target: its class changes for everybody who reads it
+            for (const auto &r : S[s].readers[x]) {
+                const int svc = S[1 - s].pos[r.first] / M;
+                add(1 - s, svc, r.second, op % M, -1);
+                add(1 - s, svc, r.second, np % M, +1);
+            }
+        S[s].pos[x] = np;
+    };
+    auto unit_max_without = [&](int s, int unit, int skip_pos) {
+        int mx = 0;
+        for (int q = unit * cost_unit; q < std::min(n_pos, (unit + 1) * cost_unit); q++)
+            if (q != skip_pos && at[s][q] >= 0) mx = std::max(mx, S[s].label[at[s][q]]);
+        return mx;
+    };
+    uint64_t rng = 0xA24BAED4963EE407ull;
+    auto next = [&]() {
+        rng ^= rng << 13;
+        rng ^= rng >> 7;
+        rng ^= rng << 17;
+        return rng;
+    };
+    const long moves = (long) rounds * (S[0].n_items + S[1].n_items);
+    const long floor_e = [&] {  // energy of a conflict-free placement: every read counted once
+        long e = 0;
+        for (int s = 0; s < 2; s++)
+            for (int i = 0; i < S[s].n_items; i++) e += (long) S[s].refs[i].size();
+        return e;
+    }();
+    for (long mv = 0; mv < moves && total > floor_e; mv++) {
+        const double T = 1.5 * std::pow(0.05 / 1.5, (double) mv / (double) moves);
+        int s = (int) (next() & 1);
+        if (S[s].n_items < 1) continue;
+        int a = (int) (next() % (uint64_t) S[s].n_items);
+        if (next() & 3) {
+            // three moves in four start from a read that currently collides (min-conflicts): take a random read and, if its
+            // class is taken twice in its service group, move either the tuple read or the reader
+            const size_t nk = S[s].refs[a].size();
+            if (nk == 0) continue;
+            const int k = (int) (next() % nk), tgt = S[s].refs[a][k];
+            if (cell(s, S[s].pos[a] / M, k, S[1 - s].pos[tgt] % M) < 2) continue;
+            if (next() & 1) {
+                a = tgt;
+                s = 1 - s;
+            }
+        }
+        const int q = (int) (next() % (uint64_t) n_pos), pa = S[s].pos[a];
+        if (q == pa) continue;
+        const int b = at[s][q];
+        if (b >= 0 && S[s].label[a] != S[s].label[b]) continue;
+        if (b < 0 && q / cost_unit != pa / cost_unit) {
+            if (s == 1) continue;  // group tuples keep their wavefront pass (the row phase stays balanced)
+            if (unit_max_without(s, q / cost_unit, -1) < S[s].label[a]) continue;  // would lengthen that wavefront pass
+        }
+        const long before = total;
+        move(s, a, q);
+        if (b >= 0) move(s, b, pa);
+        const long delta = total - before;
+        if (delta > 0 && (double) (next() >> 11) * (1.0 / 9007199254740992.0) >= std::exp(-(double) delta / T)) {
+            if (b >= 0) move(s, b, q);
+            move(s, a, pa);
+        } else {
+            at[s][q] = a;
+            at[s][pa] = b;
+        }
+    }
+    return total - floor_e;
+}
+
+bool admm_placement_qc(const Code &c, AdmmBlockPlacement &P) {
+    const AdmmLayout &A = c.admm;
+    const int L = P.L;
+    QcInfo qc;
+    if (!code_detect_qc(c, qc)) return false;
+    const int Z = qc.Z;
+    const int g = std::gcd(Z, 32), q = Z / g;
+    if (g < 2 || std::gcd(q, g) != 1 || L % g || 32 % g) return false;
+    for (int gi = 0; gi < A.n_grp; gi++)
+        if (A.grp_type[gi] != 3) return false;  // one- / two-variable checks: the annealed path handles them
+    // ---- labels: group gi = (proto G, copy i), variable v = (proto Pv, copy j) ---------------------------------------
+    // admm_layout_build walks the check rows in order; row (R, i) of degree d yields groups t = 0..d-3 and auxiliaries
+    // t = 0..d-4, so the proto index is (block row, t) and the copy index the row inside the block.
+    std::vector<int> g_proto(A.n_grp), g_copy(A.n_grp), v_proto(A.n_var, -1), v_copy(A.n_var, -1);
+    std::vector<int> gbase(qc.mb + 1, 0), abase(qc.mb + 1, 0);
+    for (int R = 0; R < qc.mb; R++) {
+        const int d = c.row_ptr[R * Z + 1] - c.row_ptr[R * Z];
+        if (d < 3) return false;
+        gbase[R + 1] = gbase[R] + (d - 2);
+        abase[R + 1] = abase[R] + (d - 3);
+    }
+    const int n_gproto = gbase[qc.mb], n_vproto = qc.nb + abase[qc.mb];
+    {
+        int gi = 0, aux = c.n;
+        for (int r = 0; r < c.m; r++) {
+            const int R = r / Z, i = r % Z, d = c.row_ptr[r + 1] - c.row_ptr[r];
+            if (d != gbase[R + 1] - gbase[R] + 2) return false;
+            for (int t = 0; t < d - 2; t++, gi++) {
+                g_proto[gi] = gbase[R] + t;
+                g_copy[gi] = i;
+            }
+            for (int t = 0; t < d - 3; t++, aux++) {
+                v_proto[aux] = qc.nb + abase[R] + t;
+                v_copy[aux] = i;
+            }
+        }
+        if (gi != A.n_grp || aux != A.n_var) return false;
+        for (int v = 0; v < c.n; v++) {
+            v_proto[v] = v / Z;
+            v_copy[v] = v % Z;
+        }
+    }
+    // ---- tuples: copies {x : x mod q = cq}, ordered by x mod g -------------------------------------------------------
+    const int n_vt = n_vproto * q, n_gt = n_gproto * q;
+    auto vt_of = [&](int v) { return v_proto[v] * q + v_copy[v] % q; };
+    auto gt_of = [&](int gi) { return g_proto[gi] * q + g_copy[gi] % q; };
+    TupleSide S[2];  // side 0 = variable tuples (read group tuples, list entry k), side 1 = group tuples (read variable tuples, member k)
+    S[0].n_items = n_vt;
+    S[1].n_items = n_gt;
+    S[0].refs.assign(n_vt, {});
+    S[1].refs.assign(n_gt, {});
+    S[0].label.assign(n_vt, 0);
+    S[1].label.assign(n_gt, 0);
+    // every member of a tuple must read the same tuple through entry k, at pairwise different offsets (x mod g):
+    // that is what the cyclic structure promises; verified here member by member, any surprise -> annealed path
+    for (int v = 0; v < A.n_var; v++) {
+        const int tv = vt_of(v), len = admm_llen(A, v);
+        if (S[0].refs[tv].empty() && len > 0) {
+            S[0].refs[tv].assign(len, -1);
+            S[0].label[tv] = len;
+        }
+        if ((int) S[0].refs[tv].size() != len) return false;
+        for (int k = 0; k < len; k++) {
+            const int gi = A.var_grp[A.var_ptr[v] + k] >> 2;
+            if (S[0].refs[tv][k] < 0) S[0].refs[tv][k] = gt_of(gi);
+            if (S[0].refs[tv][k] != gt_of(gi)) return false;
+        }
+    }
+    for (int gi = 0; gi < A.n_grp; gi++) {
+        const int tg = gt_of(gi);
+        int mem[3];
+        admm_members(A, gi, mem);
+        if (S[1].refs[tg].empty()) S[1].refs[tg].assign(3, -1);
+        for (int k = 0; k < 3; k++) {
+            if (S[1].refs[tg][k] < 0) S[1].refs[tg][k] = vt_of(mem[k]);
+            if (S[1].refs[tg][k] != vt_of(mem[k])) return false;
+        }
+    }
+    // offsets inside a tuple: the g members read g different offsets of the target tuple
+    {
+        std::vector<int> mask;
+        mask.assign((size_t) n_vt * 8, 0);
+        for (int v = 0; v < A.n_var; v++)
+            for (int k = 0; k < admm_llen(A, v) && k < 8; k++) {
+                const int gi = A.var_grp[A.var_ptr[v] + k] >> 2;
+                int &mk = mask[(size_t) vt_of(v) * 8 + k];
+                if (mk & (1 << (g_copy[gi] % g))) return false;
+                mk |= 1 << (g_copy[gi] % g);
+            }
+        for (int v = 0; v < A.n_var; v++)
+            if (admm_llen(A, v) > 8) return false;
+        mask.assign((size_t) n_gt * 3, 0);
+        for (int gi = 0; gi < A.n_grp; gi++) {
+            int mem[3];
+            admm_members(A, gi, mem);
+            for (int k = 0; k < 3; k++) {
+                int &mk = mask[(size_t) gt_of(gi) * 3 + k];
+                if (mk & (1 << (v_copy[mem[k]] % g))) return false;
+                mk |= 1 << (v_copy[mem[k]] % g);
+            }
+        }
+    }
+    // ---- tuple positions ---------------------------------------------------------------------------------------------
+    const int M = 32 / g;            // tuples per 32-lane service group = number of classes
+    const int per_pass = L / g;      // tuple positions per pass
+    const int unit = 64 / g;         // tuple positions per (pass, wavefront)
+    const int n_pass = std::max(P.n_vpass, P.n_gpass);
+    const int n_pos = n_pass * per_pass;
+    if (n_vt > P.n_vpass * per_pass || n_gt + 1 > P.n_gpass * per_pass || L % 64) return false;
+    // start: variable tuples sorted by list length, cut into wavefront-pass units, units dealt to the wavefronts
+    // longest first onto the least loaded wavefront (its passes fill in order)
+    {
+        std::vector<int> order(n_vt);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S[0].label[x] > S[0].label[y]; });
+        const int waves = L / 64;
+        std::vector<int> load(waves, 0), used(waves, 0);
+        S[0].pos.assign(n_vt, -1);
+        for (int u0 = 0; u0 < n_vt; u0 += unit) {
+            int best = -1;
+            for (int w = 0; w < waves; w++)
+                if (used[w] < P.n_vpass && (best < 0 || load[w] < load[best])) best = w;
+            if (best < 0) return false;
+            const int pass = used[best]++;
+            load[best] += S[0].label[order[u0]];
+            for (int x = u0; x < std::min(n_vt, u0 + unit); x++) S[0].pos[order[x]] = pass * per_pass + best * unit + (x - u0);
+        }
+        // group tuples: pass-major, the last (partial) pass goes to the wavefronts with the lightest v-update load
+        std::vector<int> worder(waves);
+        std::iota(worder.begin(), worder.end(), 0);
+        std::stable_sort(worder.begin(), worder.end(), [&](int x, int y) { return load[x] < load[y]; });
+        S[1].pos.assign(n_gt, -1);
+        int x = 0;
+        for (int pass = 0; pass < P.n_gpass && x < n_gt; pass++) {
+            const bool last = (n_gt - x) < per_pass;
+            for (int wi = 0; wi < waves && x < n_gt; wi++) {
+                const int w = last ? worder[wi] : wi;
+                for (int o = 0; o < unit && x < n_gt; o++, x++) S[1].pos[x] = pass * per_pass + w * unit + o;
+            }
+        }
+    }
+    // group tuples carry no label constraint except "stay in the same pass occupancy": label = pass so the row phase
+    // keeps its per-wavefront pass counts; variable tuples: label = list length
+    for (int t = 0; t < n_gt; t++) S[1].label[t] = 0;
+    const long residual = tuple_joint_placement(S, n_pos, M, unit, 10000);
+    if (getenv("ACG_ADMM_PLACEMENT_DEBUG"))
+        fprintf(stderr, "[acg_ldpc] QC placement: Z=%d tuple=%d, %d variable / %d group tuples on %d positions, residual conflict energy %ld\n",
+                Z, g, n_vt, n_gt, n_pos, residual);
+    // ---- back to threads -------------------------------------------------------------------------------------------------
+    P.var_of_slot.assign((size_t) P.n_vpass * L, -1);
+    P.cell_of_var.assign(A.n_var, 0);
+    P.slot_of_grp.assign(A.n_grp, 0);
+    for (int v = 0; v < A.n_var; v++) {
+        const int slot = S[0].pos[vt_of(v)] * g + v_copy[v] % g;
+        if (slot >= P.n_vpass * L || P.var_of_slot[slot] >= 0) return false;
+        P.var_of_slot[slot] = v;
+        P.cell_of_var[v] = slot;  // V cell = thread slot: consecutive lanes store consecutive words
+    }
+    std::vector<char> used((size_t) P.n_gpass * L, 0);
+    for (int gi = 0; gi < A.n_grp; gi++) {
+        const int slot = S[1].pos[gt_of(gi)] * g + g_copy[gi] % g;
+        if (slot >= P.n_gpass * L || used[slot]) return false;
+        used[slot] = 1;
+        P.slot_of_grp[gi] = slot;
+    }
+    P.zero_gslot = -1;
+    for (int sl = P.n_gpass * L - 1; sl >= 0 && P.zero_gslot < 0; sl--)
+        if (!used[sl]) P.zero_gslot = sl;
+    if (P.zero_gslot < 0) return false;
+    P.zero_cell = P.n_vpass * L;
+    P.n_cells = P.n_vpass * L + 1;
+    P.n3 = 0;
+    P.qc = true;
+    P.Z = Z;
+    P.tuple = g;
+    return true;
+}
+
+}  // namespace
+
+bool admm_block_placement(const Code &c, int L, bool f32, int mode, AdmmBlockPlacement &out) {
+    const AdmmLayout &A = c.admm;
+    out = AdmmBlockPlacement();
+    out.L = L;
+    out.n_gpass = (A.n_grp + 1 + L - 1) / L;  // +1: at least one padding slot that stays all-zero
+    out.n_vpass = (A.n_var + L - 1) / L;
+    bool done = false;
+    if (mode >= 2) done = admm_placement_qc(c, out);
+    if (!done) {
+        AdmmBlockPlacement fresh;
+        fresh.L = L;
+        fresh.n_gpass = out.n_gpass;
+        fresh.n_vpass = out.n_vpass;
+        out = fresh;
+        admm_placement_annealed(c, out, f32, mode >= 1);
+    }
+    admm_model_cycles(c, out, f32);
+    return true;
+}
+
 }  // namespace acg

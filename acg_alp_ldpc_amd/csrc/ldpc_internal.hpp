@@ -88,4 +88,49 @@ long placement_optimise_gather(std::vector<int> &item_at_slot, const std::vector
                                const std::vector<int> &reader_label, const std::vector<std::vector<int>> &items_of_reader, int lanes,
                                int modulus, int rounds, long *cycles_before = nullptr, long *cycles_after = nullptr);
 
+// ---- quasi-cyclic structure -----------------------------------------------------------------------------
+// H as an (m/Z) x (n/Z) array of Z x Z blocks, each zero or a cyclic-shift permutation: row k of block (R, C) has its
+// one at column (k + shift) mod Z — the reference's PermutationsMatrix (optimize_H.cpp:27-63); data/H05.txt and
+// data/optimalH.txt are 8 x 14 arrays of 20 x 20 such blocks.
+struct QcInfo {
+    int Z = 0, mb = 0, nb = 0;
+    std::vector<int> shift;  // [mb*nb], -1 = zero block
+};
+// largest Z >= 2 for which the matrix has this form (false: none)
+bool code_detect_qc(const Code &c, QcInfo &q);
+
+// ---- placement of the QP-ADMM problem on the threads / LDS of admm_block_kernel ------------------------------------
+// One workgroup of L threads owns a frame: thread l handles, in pass p, the variable var_of_slot[p*L + l] (v-update) and
+// the constraint group living in U slot p*L + l (row phase).  LDS: V[cell] (fp64/fp32 words) and U[slot][4 rows], tiled so
+// that the bank of an access is `slot mod 32` / `cell mod 32`.  A wavefront's LDS instruction is served 32 lanes at a
+// time (ds_read_b64 / ds_read_b32) or 16 (ds_write_b64) and costs as many cycles as its busiest bank has distinct
+// addresses, so the three free maps (variable -> thread slot, group -> U slot, variable -> V cell) decide the cost:
+//   mode 1 (any code)  variables sorted by list length; group slots and V cells by simulated annealing over the
+//                      modelled cycles (placement_optimise);
+//   mode 2 (QC codes)  constructive: with g = gcd(Z, 32) and gcd(Z/g, g) = 1, the g copies {i : i mod (Z/g) = c} of a
+//                      proto-variable / proto-group ("tuple") sit in g consecutive lanes ordered by i mod g.  A cyclic
+//                      shift permutes the members of a tuple among themselves in the low log2(g) bank bits, so a
+//                      tuple's accesses never collide with each other and the problem shrinks to placing tuples:
+//                      32/g tuples per 32-lane service group, whose referenced tuples must sit in distinct classes
+//                      (tuple position mod 32/g).  V cell = thread slot of the variable, U slot = thread slot of the
+//                      group, so the stores are conflict-free by construction; the tuple positions are found by a joint
+//                      search over both sides that starts from list-length-balanced wavefronts.
+struct AdmmBlockPlacement {
+    int L = 0, n_gpass = 0, n_vpass = 0;
+    int n_cells = 0;      // V cells incl. the zero cell
+    int zero_cell = 0;    // a cell that is always 0.0 (absent members of one- / two-variable checks)
+    int zero_gslot = 0;   // a U slot that is always all-zero (list padding)
+    std::vector<int> var_of_slot;  // [n_vpass*L] variable id or -1
+    std::vector<int> slot_of_grp;  // [n_grp]
+    std::vector<int> cell_of_var;  // [n_var]
+    int n3 = 0;           // mode 1: groups in slots [0, n3) are three-variable checks, the rest one-/two-variable ones
+    bool qc = false;
+    int Z = 0, tuple = 1;
+    // modelled LDS cycles per frame-sweep (one per 32-/16-lane service group and instruction; U reads count one row)
+    long cyc_u_reads = 0, cyc_v_reads = 0, cyc_v_writes = 0;
+    long ideal_u_reads = 0, ideal_v_reads = 0, ideal_v_writes = 0;  // the same with no bank conflict at all
+    int wave_cost[4] = {0, 0, 0, 0};  // v-update: sum over passes of the longest list in (pass, wavefront)
+};
+bool admm_block_placement(const Code &c, int L, bool f32, int mode, AdmmBlockPlacement &out);
+
 }  // namespace acg

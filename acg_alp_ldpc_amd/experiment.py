@@ -7,6 +7,7 @@ shards is the same set of frames for any W.  The only cross-rank step is adding 
 (merge_exp_results, experiment.h:70-78) — no data-path collective.
 """
 import ctypes as C
+import threading
 import time
 
 import numpy as np
@@ -118,3 +119,35 @@ def run_experiment_sharded(decoder, codewords, H, snr, frames, rank=0, world=1, 
     dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
     total = ExperimentResult.from_vector(v.cpu().numpy(), time_sec=time.time() - t0, kernel_ms=local.kernel_ms)
     return local, total
+
+
+def run_experiment_inproc(make_decoder, codewords, H, snr, frames, devices, noise="device", seed=1):
+    """All GPUs of a node from ONE process, no torch.distributed: one host thread and one decoder per device (what
+    multithread_experiment does with pthreads, experiment.h:125-139), shard g = the contiguous global range
+    shard_range(frames, g, len(devices)), counters merged on the host (merge_exp_results, experiment.h:70-78).
+
+    make_decoder(device) -> a Decoder bound to that device.  Returns (per-shard results, merged total)."""
+    devices = list(devices)
+    W = len(devices)
+    locals_ = [None] * W
+    errs = []
+
+    def work(g):
+        try:
+            dec = make_decoder(devices[g])
+            lo, cnt = shard_range(int(frames), g, W)
+            locals_[g] = run_experiment(dec, codewords, H, snr, frames=cnt, first_frame=lo, noise=noise, seed=seed)
+        except Exception as e:  # noqa: BLE001 - re-raised below in the calling thread
+            errs.append(e)
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(g,)) for g in range(W)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    total = ExperimentResult()
+    for r in locals_:
+        merge_exp_results(total, r)
+    total.time_sec = time.time() - t0
+    return locals_, total

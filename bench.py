@@ -4,34 +4,62 @@ sum-product BP, 1M synthetic AWGN frames per GPU (BASELINE configs[1]), 1/2/4/8 
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          # one process per GPU
+    python bench.py --inproc N --steps K --warmup W                     # one process, N GPUs, no torch.distributed
 
-A "step" is one pass of the hot path (acg_ldpc_decode_batch_dev) over one resident batch of
-`--frames` noisy frames per GPU.  The batch (channel symbols, fp32) is generated on the device
-before the timed region; inputs and outputs stay in HBM.  Frames are independent, so rank r owns
-global frames [r*F, (r+1)*F) — weak scaling, no data-path collective; the only
-cross-rank traffic is the barrier / MAX of the timing and a sum of a few counters.
+A "step" is one pass of the hot path (acg_ldpc_decode_batch_dev) over one resident batch of `--frames` noisy
+frames per GPU.  The batch (channel symbols, fp32) is generated on the device before the timed region; inputs and
+outputs stay in HBM.  Frames are independent, so shard s owns global frames [s*F, (s+1)*F) — weak scaling, no
+data-path collective.  Across processes the only traffic is the barrier, a MAX of the wall time and
+a SUM of four counters, carried by gloo on CPU tensors (no RCCL anywhere: north_star).
 
-Headline `value`: FIXED WORK — every frame runs all 50 flooding iterations (output latched at its
-first zero syndrome), i.e. nothing is skipped; this is the figure the streamed-message roofline
-model of SURVEY §8(d) (745,155 B/frame) is written for.  The reference's own semantics (stop a
-frame at its first zero syndrome, bp.h:195-196) is timed too and reported under "early_exit",
-next to the reference CPU decoder ("cpu_baseline"), which only exists in that form.
+Headline `value`: FIXED WORK — every frame runs all 50 flooding iterations (output latched at its first zero
+syndrome), nothing is skipped.  The reference's own stopping rule (bp.h:195-196) is timed under "early_exit".
 
-The roofline object is the streamed-equivalent HBM figure: the fused kernel keeps messages in
-LDS, so `achieved` may exceed the HBM peak and is NOT HBM utilisation (see DESIGN.md §5);
-`traffic` is the PMC-measured HBM traffic per launch when profiles/ holds one for this config.
+Every other claim of DESIGN.md is a side object of the same JSON line, measured in the same run:
+  "streamed"      the HBM-resident engine north_star sketches (messages [edge][frame] in HBM): real HBM roofline
+  "minsum_0.75"   north_star's named variant (not in the reference: parity unpinned)
+  "configs[2]"    H05 QP-ADMM(1.95, 0.5) fp64, 100 sweeps, 1M frames — with its own roofline (LDS array)
+  "configs[4]"    synthetic (3,6)-regular 5000 x 10000, min-sum 50 iterations, 32768 frames per GPU: fused and streamed
+  "monte_carlo"   acg_ldpc_mc_run: AWGN generated in the kernel + classification + D2H of the counters — the
+                  metric exactly as SURVEY §8(d) words it
+  "cpu_baseline", "cpu_baseline_qpadmm"   the reference's bp.h / qp_admm.h on this host's cores
+  "pmc"           rocprofv3 counter passes taken by THIS run (child processes) that the roofline fractions use
+
+Roofline fractions are utilisations of the resource that binds each kernel (<= 1): VALU issue for the LDS-resident
+BP kernels, the LDS array for QP-ADMM, HBM for the streamed engine.  The SURVEY §8(d) streamed-model figure of an
+LDS-resident kernel is kept as `streamed_equiv_frac`; it is NOT a utilisation and may exceed 1.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_CU, N_SIMD = 256, 1024   # 256 CUs x 4 SIMD-32
+NOMINAL_CLK_HZ = 2.4e9
+# VALU issue prices, cycles per wave64 instruction per SIMD with several waves resident (tools/microbench/valu_rates.hip,
+# output committed as profiles/r02_valu_rates.txt; MI355X_MICROARCH.md cycle-constants table: fma 2 on the SIMD-32)
+CYC_VALU = 2.0
+CYC_TRANS = 8.0            # v_exp_f32 / v_log_f32 alone (quarter rate); the mul+exp PAIR measures 10-12
+CYC_VALU_F64 = 4.0         # fp64 add / mul / fma / max: half rate
+
+PROBE_ITEMS = ("bp_fused", "bp_streamed", "ms_streamed", "qpadmm", "c5_block_ms", "c5_streamed_ms")
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
+              ("write", ["WRITE_SIZE", "GRBM_GUI_ACTIVE"]),
+              ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE",
+                      "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"]),
+              # optional (a failure of this pass only drops the fp64 split of the QP-ADMM VALU estimate)
+              ("f64", ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]))
+PMC_OPTIONAL = ("f64",)
 
 
 def bp_bytes_per_frame(n, E, iters, b=4, b_in=4):
@@ -44,9 +72,23 @@ def admm_bytes_per_frame(n, n_con, n_var, iters, b=8, b_in=4):
     return n * b_in + iters * (5 * n_con + 3 * n_var) * b + (n + 7) // 8
 
 
+def csrc_sha():
+    """hash of the kernel sources: a committed counter file is only used for the code it was taken from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "acg_alp_ldpc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baselines: the reference's own decoders (oracle/_ref, compiled from /root/reference in the build container) or,
+# if that .so did not travel, the oracle port — one single-threaded process per host core, disjoint frame ranges
+# (BP's global node counter forbids threads, SURVEY D5), on a bounded sample of the same workload.
 def cpu_baseline_worker(args):
-    """one process = one single-threaded reference decoder (BP's global node counter forbids threads)"""
-    kind, Hm, y, snr, max_iter = args
+    kind, algo, Hm, y, snr, max_iter, alpha, mu = args
     if kind == "reference":
         from oracle.pyoracle import Ref
         d = Ref()
@@ -54,308 +96,621 @@ def cpu_baseline_worker(args):
         from oracle.pyoracle import Oracle
         d = Oracle()
     t0 = time.time()
-    bits, ok, _ = d.bp_decode(Hm, y, snr, max_iter)
+    if algo == "bp":
+        _, ok, _ = d.bp_decode(Hm, y, snr, max_iter)
+    else:
+        _, ok, _ = d.qpadmm_decode(Hm, y, snr, alpha, mu, max_iter, 1e-5)
     return time.time() - t0, int(ok.sum())
 
 
-def cpu_baseline(Hm, cws, snr, max_iter, per_proc):
-    """reference (oracle/_ref, built from /root/reference in the build container) or, if that .so did not
-    travel, the oracle port — timed on this host's cores on a bounded sample of the same workload."""
+def cpu_baseline(algo, Hm, cws, snr, max_iter, target_s, alpha=0.0, mu=0.0):
+    """sample sized by a short calibration so the timed part is about target_s seconds of wall time on every core"""
     import multiprocessing as mp
     import numpy as np
     from oracle.pyoracle import Oracle, ref_available
     o = Oracle()
     kind = "reference" if ref_available() else "port"
-    cores = min(os.cpu_count() or 1, 16)
-    if kind == "port":
-        per_proc *= 8  # the flat restatement is roughly an order of magnitude faster per core
-    total = per_proc * cores
-    y = o.transmit_frames(cws[np.arange(total) % len(cws)], snr, first_seed=1)
-    chunks = [(kind, Hm, y[i * per_proc:(i + 1) * per_proc], snr, max_iter) for i in range(cores)]
+    cores = os.cpu_count() or 1
+    cal = 8
+    ycal = o.transmit_frames(cws[np.arange(cal) % len(cws)], snr, first_seed=1)
     ctx = mp.get_context("spawn")
-    t0 = time.time()
     with ctx.Pool(cores) as pool:
-        res = pool.map(cpu_baseline_worker, chunks)
-    wall = time.time() - t0
-    busy = max(r[0] for r in res)
+        # start the workers, load the .so, and calibrate with every core busy (the rate per core depends on that)
+        t0 = time.time()
+        pool.map(cpu_baseline_worker, [(kind, algo, Hm, ycal, snr, max_iter, alpha, mu)] * cores, chunksize=1)
+        pool.map(cpu_baseline_worker, [(kind, algo, Hm, ycal, snr, max_iter, alpha, mu)] * cores, chunksize=1)
+        res = pool.map(cpu_baseline_worker, [(kind, algo, Hm, ycal, snr, max_iter, alpha, mu)] * cores, chunksize=1)
+        per_frame = max(r[0] for r in res) / cal
+        per_proc = int(min(20000, max(cal, target_s / max(per_frame, 1e-6))))
+        total = per_proc * cores
+        y = o.transmit_frames(cws[np.arange(total) % len(cws)], snr, first_seed=1)
+        chunks = [(kind, algo, Hm, y[i * per_proc:(i + 1) * per_proc], snr, max_iter, alpha, mu) for i in range(cores)]
+        t0 = time.time()
+        res = pool.map(cpu_baseline_worker, chunks, chunksize=1)
+        wall = time.time() - t0
+    what = ("BeliefPropagationDecoder(%d) (algo/bp.h:208-222)" % max_iter if algo == "bp" else
+            "QPADMMDecoder(%g, %g, %d, 1e-5) (algo/qp_admm.h:104-194)" % (alpha, mu, max_iter))
     return {
-        "value": total / busy, "unit": "frames/s", "cores": cores, "kind": kind,
-        "sample": "%d frames (%d per process, %d single-threaded processes) of the same H05/AWGN workload at "
-                  "%.1f dB, %s BeliefPropagationDecoder(%d) with its early exit; slowest process %.1f s, "
-                  "pool wall %.1f s" % (total, per_proc, cores, snr,
-                                       "reference" if kind == "reference" else "oracle port of", max_iter, busy, wall),
+        "value": total / wall, "unit": "frames/s", "cores": cores, "kind": kind,
+        "sample": "%d frames (%d per process, %d single-threaded processes = all host cores) of the same H05/AWGN workload "
+                  "at %.1f dB, %s %s with its own stopping rule; pool wall %.1f s (slowest process %.1f s)"
+                  % (total, per_proc, cores, snr, "the reference's" if kind == "reference" else "oracle port of",
+                     what, wall, max(r[0] for r in res)),
         "decoded_ok": sum(r[1] for r in res), "frames": total,
     }
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class Dev:
+    """one GPU driven by this process"""
+
+    def __init__(self, idx, shard):
+        import torch
+        self.idx, self.shard = idx, shard
+        with torch.cuda.device(idx):
+            self.stream = torch.cuda.Stream(device=idx)   # a dedicated (non-null) HIP stream: kernels and timing events
+
+
+class Rig:
+    """The set of GPUs of this job: `world` processes (torch.distributed, gloo control plane) x len(devs) GPUs each."""
+
+    def __init__(self, a):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        ndev = max(1, torch.cuda.device_count())
+        if a.inproc:
+            if self.world > 1:
+                raise SystemExit("--inproc runs in ONE process; do not combine it with torch.distributed.run")
+            if a.inproc > ndev and not os.environ.get("ACG_BENCH_SHARE_GPU"):
+                raise SystemExit("--inproc %d but only %d GPUs visible" % (a.inproc, ndev))
+            self.devs = [Dev(i % ndev, i) for i in range(a.inproc)]   # (ACG_BENCH_SHARE_GPU: rehearsal on a 1-GPU box)
+            self.launcher = "inproc (one process, %d GPUs, asynchronous launches from one host thread)" % a.inproc
+        else:
+            if self.world != a.gpus and self.world > 1:
+                raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, self.world))
+            if a.gpus > 1 and self.world == 1:
+                raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU) or use --inproc N")
+            self.devs = [Dev(local_rank % ndev, self.rank)]
+            self.launcher = "torch.distributed.run, one process per GPU" if self.world > 1 else "single process"
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            # control plane only (barrier, MAX of one double, SUM of four integers) -> gloo on CPU tensors.
+            # ACG_BENCH_BACKEND=nccl is kept for comparison; nothing on the data path ever uses a collective.
+            self.backend = os.environ.get("ACG_BENCH_BACKEND", "gloo")
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.devs[0].idx)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.devs[0].idx))
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+        self.nshards = self.world * len(self.devs)
+
+    def sync_local(self):
+        for d in self.devs:
+            self.torch.cuda.synchronize(d.idx)
+
+    def barrier(self):
+        self.sync_local()
+        if self.dist:
+            self.dist.barrier()
+        self.sync_local()
+
+    def _red(self, vals, op, dtype):
+        if not self.dist:
+            return vals
+        t = self.torch.tensor(vals, dtype=dtype, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=op)
+        return t.tolist()
+
+    def max_time(self, dt):
+        return self._red([dt], self.dist.ReduceOp.MAX, self.torch.float64)[0] if self.dist else dt
+
+    def sum_ints(self, v):
+        return [int(x) for x in (self._red(list(v), self.dist.ReduceOp.SUM, self.torch.int64) if self.dist else v)]
+
+    def timed(self, step, steps, warmup):
+        """step(dev) enqueues ONE step on dev.stream.  -> (seconds for `steps` steps, max over ranks; mean kernel ms)"""
+        torch = self.torch
+        for _ in range(warmup):
+            for d in self.devs:
+                step(d)
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+              for _ in self.devs]
+        self.barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            for i, d in enumerate(self.devs):
+                with torch.cuda.device(d.idx):
+                    ev[i][s][0].record(d.stream)   # HIP events on the stream the kernel is launched on
+                    step(d)
+                    ev[i][s][1].record(d.stream)
+        self.barrier()
+        dt = self.max_time(time.perf_counter() - t0)
+        kms = sum(e0.elapsed_time(e1) for per in ev for e0, e1 in per) / (steps * len(self.devs))
+        return dt, kms
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+class Batch:
+    """per-GPU resident buffers of one workload: symbols in, packed words / flags / sweep counts out"""
+
+    def __init__(self, rig, H, cws, F):
+        import numpy as np
+        torch = rig.torch
+        self.rig, self.H, self.cws, self.F = rig, H, cws, F
+        self.n, self.nw = H.n, (H.n + 31) // 32
+        self.y, self.bits, self.ok, self.its, self.cwp = {}, {}, {}, {}, {}
+        pad = np.zeros((cws.shape[0], self.nw * 32), dtype=np.uint8)
+        pad[:, :H.n] = cws
+        packed = np.packbits(pad, axis=1, bitorder="little").view(np.int32).copy()
+        for d in rig.devs:
+            dev = "cuda:%d" % d.idx
+            self.y[d.shard] = torch.empty((F, self.n), dtype=torch.float32, device=dev)
+            self.bits[d.shard] = torch.zeros((F, self.nw), dtype=torch.int32, device=dev)
+            self.ok[d.shard] = torch.zeros(F, dtype=torch.uint8, device=dev)
+            self.its[d.shard] = torch.zeros(F, dtype=torch.int32, device=dev)
+            self.cwp[d.shard] = torch.from_numpy(packed).to(dev)
+
+    def gen_noise(self, decs, snr, seed=1):
+        """fills y of every shard with the global frames [shard*F, (shard+1)*F) of the Philox AWGN stream"""
+        import ctypes as C
+        from acg_alp_ldpc_amd._lib import McCfg, check, lib
+        for d in self.rig.devs:
+            h, _ = decs[d.shard].handle(self.H)
+            cfg = McCfg()
+            cfg.frames, cfg.first_frame, cfg.snr, cfg.seed, cfg.noise = self.F, d.shard * self.F, snr, seed, 0
+            cfg.codewords, cfg.n_codewords = self.cws.ctypes.data, self.cws.shape[0]
+            check(lib().acg_ldpc_awgn_dev(h, C.byref(cfg), self.y[d.shard].data_ptr(), d.stream.cuda_stream))
+        self.rig.sync_local()
+
+    def step_fn(self, decs, snr, frames=None):
+        F = self.F if frames is None else frames
+
+        def step(d):
+            s = d.shard
+            decs[s].decode_batch_dev(self.H, self.y[s].data_ptr(), False, F, snr, self.bits[s].data_ptr(),
+                                     self.ok[s].data_ptr(), self.its[s].data_ptr(), d.stream.cuda_stream)
+        return step
+
+    def quality(self, frames=None):
+        """FER / mean sweeps of the batch currently in (bits, ok, its), all shards.  (QP-ADMM: ok is always 1; a wrong
+        word is counted by the compare.)"""
+        torch = self.rig.torch
+        F = self.F if frames is None else frames
+        tot = [0, 0, 0, 0]
+        for d in self.rig.devs:
+            s = d.shard
+            with torch.cuda.device(d.idx):
+                idx = (torch.arange(F, device=self.y[s].device, dtype=torch.int64) + s * self.F) % self.cwp[s].shape[0]
+                good = (self.bits[s][:F] == self.cwp[s][idx]).all(dim=1) & (self.ok[s][:F] == 1)
+                v = torch.stack([good.sum(), self.ok[s][:F].sum(), self.its[s][:F].sum()]).to(torch.int64).tolist()
+            tot = [tot[0] + v[0], tot[1] + v[1], tot[2] + v[2], tot[3] + F]
+        c, k, i, t = self.rig.sum_ints(tot)
+        return {"fer": (t - c) / t, "undetected": k - c, "mean_iters": i / t, "frames": t}
+
+
+def make_decoders(rig, ctor):
+    return {d.shard: ctor(d.idx) for d in rig.devs}
+
+
+def close_decoders(decs):
+    for x in decs.values():
+        x.close()
+
+
+def decode_leg(rig, batch, ctor, snr, steps, warmup, frames=None, noise_seed=1):
+    """time `steps` steps of one decoder configuration on every shard -> dict"""
+    decs = make_decoders(rig, ctor)
+    batch.gen_noise(decs, snr, noise_seed)
+    F = batch.F if frames is None else frames
+    dt, kms = rig.timed(batch.step_fn(decs, snr, F), steps, warmup)
+    q = batch.quality(F)
+    lay = next(iter(decs.values())).layout(batch.H)
+    close_decoders(decs)
+    return {"value": rig.nshards * F * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "kernel_ms": kms,
+            "steps": steps, "frames_per_gpu": F, "snr_db": snr, "fer": q["fer"], "undetected_errors": q["undetected"],
+            "mean_iters": q["mean_iters"], "layout": lay}
+
+
+def mc_leg(rig, H, cws, ctor, snr, F, steps):
+    """acg_ldpc_mc_run (AWGN in the kernel, classification, D2H of the seven counters): one host thread per GPU, as the
+    reference's multithread_experiment drives its workers (experiment.h:125-139)"""
+    import acg_alp_ldpc_amd as A
+    decs = make_decoders(rig, ctor)
+    res = {}
+
+    def work(d, n):
+        for k in range(n):
+            r = A.run_experiment(decs[d.shard], cws, H, snr, frames=F, first_frame=d.shard * F, noise="device", seed=1 + k)
+            res[d.shard] = r
+
+    def run(n):
+        th = [threading.Thread(target=work, args=(d, n)) for d in rig.devs]
+        [t.start() for t in th]
+        [t.join() for t in th]
+
+    run(1)
+    rig.barrier()
+    t0 = time.perf_counter()
+    run(steps)
+    rig.barrier()
+    dt = rig.max_time(time.perf_counter() - t0)
+    v = [0] * 7
+    for r in res.values():
+        v = [x + int(y) for x, y in zip(v, r.as_vector())]
+    v = rig.sum_ints(v)
+    close_decoders(decs)
+    return {"value": rig.nshards * F * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "frames_per_gpu": F, "snr_db": snr, "fer": (v[2] - v[0]) / v[2], "pseudo_codewords": v[1],
+            "mean_iters": v[6] / v[2], "raw_channel_errors_per_frame": v[3] / v[2]}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# workloads shared by the main run and the PMC probe child
+def ctor_table(A, a):
+    eng_s = A.ENGINE_STREAMED
+    return {
+        "bp_fused": lambda dev: A.BeliefPropagationDecoder(a.iters, early_exit=False, device=dev, lanes_per_frame=a.lanes),
+        "bp_exit": lambda dev: A.BeliefPropagationDecoder(a.iters, early_exit=True, device=dev, lanes_per_frame=a.lanes),
+        "bp_streamed": lambda dev: A.BeliefPropagationDecoder(a.iters, early_exit=False, device=dev, engine=eng_s),
+        "ms_fused": lambda dev: A.MinSumDecoder(a.iters, 0.75, early_exit=False, device=dev, lanes_per_frame=a.lanes),
+        "ms_exit": lambda dev: A.MinSumDecoder(a.iters, 0.75, early_exit=True, device=dev, lanes_per_frame=a.lanes),
+        "ms_streamed": lambda dev: A.MinSumDecoder(a.iters, 0.75, early_exit=False, device=dev, engine=eng_s),
+        "qpadmm": lambda dev: A.QPADMMDecoder(a.alpha, a.mu, 100, 0.0, device=dev),          # eps 0: every frame runs 100 sweeps
+        "qpadmm_exit": lambda dev: A.QPADMMDecoder(a.alpha, a.mu, 100, 1e-5, device=dev),
+        "c5_block_ms": lambda dev: A.MinSumDecoder(50, 0.75, early_exit=False, device=dev),
+        "c5_block_spa": lambda dev: A.BeliefPropagationDecoder(50, early_exit=False, device=dev),
+        "c5_streamed_ms": lambda dev: A.MinSumDecoder(50, 0.75, early_exit=False, device=dev, engine=eng_s),
+    }
+
+
+def load_h05(A, a):
+    H = A.read_pcm(a.matrix)
+    G, ok = H.get_orthogonal()
+    assert ok
+    return H, A.gen_random_codewords(G, 8192, 239239239)
+
+
+def load_c5(A):
+    import numpy as np
+    H = A.ParityCheckMatrix(A.regular_ldpc(5000, 10000, 3, 6, seed=1))
+    return H, np.zeros((1, 10000), dtype=np.uint8)   # all-zero codeword (both decoders are symmetric, SURVEY H7)
+
+
+def pmc_probe_child(a):
+    """run under `rocprofv3 --pmc ... -- python3 bench.py --pmc-probe`: every probed kernel exactly twice, in PROBE_ITEMS order"""
+    import acg_alp_ldpc_amd as A
+    rig = Rig(a)
+    T = ctor_table(A, a)
+    H, cws = load_h05(A, a)
+    b = Batch(rig, H, cws, a.frames)
+    items = [x for x in PROBE_ITEMS if not a.probe_items or x in a.probe_items.split(",")]
+    for name in items:
+        if name.startswith("c5_"):
+            continue
+        decs = make_decoders(rig, T[name])
+        b.gen_noise(decs, a.snr)
+        for _ in range(2):
+            b.step_fn(decs, a.snr)(rig.devs[0])
+        rig.sync_local()
+        close_decoders(decs)
+    if any(x.startswith("c5_") for x in items):
+        del b
+        H5, cw5 = load_c5(A)
+        b5 = Batch(rig, H5, cw5, a.c5_frames)
+        for name in items:
+            if not name.startswith("c5_"):
+                continue
+            decs = make_decoders(rig, T[name])
+            b5.gen_noise(decs, 2.0)
+            for _ in range(2):
+                b5.step_fn(decs, 2.0)(rig.devs[0])
+            rig.sync_local()
+            close_decoders(decs)
+    print("PMC_PROBE_DONE " + ",".join(items))
+
+
+PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
+    "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false", 0), "bp_streamed": ("bp_streamed_kernel<float, 0>", 0),
+    "ms_streamed": ("bp_streamed_kernel<float, 1>", 0), "qpadmm": ("admm_block_kernel<double, false", 0),
+    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false", 0), "c5_streamed_ms": ("bp_streamed_kernel<float, 1>", 1),
+}
+
+
+def pmc_one_pass(a, tag, ctrs, left, env, out):
+    """one rocprofv3 --pmc run of the probe child; fills out["items"]; -> error text or None"""
+    import csv
+    import glob
+    import signal
+    tmp = tempfile.mkdtemp(prefix="acg_pmc_%s_" % tag, dir="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", tmp, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-probe", "--frames", str(a.frames), "--c5-frames",
+           str(a.c5_frames), "--snr", str(a.snr), "--iters", str(a.iters), "--alpha", str(a.alpha), "--mu", str(a.mu),
+           "--matrix", a.matrix, "--lanes", str(a.lanes)]
+    try:
+        p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                             start_new_session=True)
+        try:
+            log, _ = p.communicate(timeout=min(left, 240))
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)   # exactly the process group this function started
+            p.communicate()
+            return "counter pass '%s' timed out" % tag
+        if p.returncode != 0 or "PMC_PROBE_DONE" not in log:
+            return "counter pass '%s' failed (rc %s): %s" % (tag, p.returncode, log[-300:])
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return "counter pass '%s' wrote no counter_collection.csv" % tag
+        rows = []
+        for f in files:
+            rows += list(csv.DictReader(open(f)))
+        per = {}   # kernel name -> dispatch id -> counter -> value (summed over the rows of one dispatch)
+        for r in rows:
+            did = int(r.get("Dispatch_Id", r.get("Dispatch_ID", 0)))
+            dct = per.setdefault(r["Kernel_Name"], {}).setdefault(did, {})
+            dct[r["Counter_Name"]] = dct.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        for item, (pat, pos) in PROBE_KERNEL.items():
+            ks = [k for k in per if pat in k]
+            if not ks:
+                continue
+            disp = sorted(per[ks[0]].items())
+            mine = disp[2 * pos:2 * pos + 2]
+            for c in ctrs:
+                vals = [d[c] for _, d in mine if c in d]
+                if vals:
+                    out["items"][item][c] = sum(vals) / len(vals)
+    except FileNotFoundError:
+        return "rocprofv3 not found"
+    finally:
+        subprocess.call(["rm", "-rf", tmp])
+    return None
+
+
+def pmc_collect(a, budget_s):
+    """Three rocprofv3 counter passes (each counter group alone, kernel-trace only) over the probe child.
+    -> {"items": {item: {counter: mean per launch}}, ...} or {"error": ...}"""
+    out = {"source": "rocprofv3 --pmc passes run by this bench.py process (child: bench.py --pmc-probe)", "csrc_sha": csrc_sha(),
+           "frames": a.frames, "c5_frames": a.c5_frames, "items": {k: {} for k in PROBE_ITEMS}}
+    t_start = time.time()
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for tag, ctrs in PMC_PASSES:
+        left = budget_s - (time.time() - t_start)
+        err = None
+        if left < 30:
+            err = "time budget for the counter passes exhausted before pass '%s'" % tag
+        else:
+            err = pmc_one_pass(a, tag, ctrs, left, env, out)
+        if err and tag in PMC_OPTIONAL:
+            out.setdefault("notes", []).append(err)
+        elif err:
+            out["error"] = err
+            break
+    out["seconds"] = time.time() - t_start
+    return out
+
+
+def pmc_lookup(pmc, item):
+    if pmc and pmc.get("items", {}).get(item):
+        return pmc["items"][item], pmc.get("source")
+    return None, None
+
+
+def roofline_fused(c, src, kms, F, bpf, fp64=False):
+    """LDS-resident kernels: VALU-issue and LDS-array utilisation from the counters of this launch shape"""
+    r = {"streamed_equiv_frac": F * bpf / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "streamed_equiv_bytes_per_frame": bpf,
+         "kernel_ms": kms, "counters_from": src}
+    if not c or "SQ_INSTS_VALU" not in c:
+        r.update({"bound": "valu_issue", "achieved": None, "peak": N_SIMD * NOMINAL_CLK_HZ / 1e9, "unit": "Gcycle/s", "frac": None,
+                  "traffic": None, "note": "no counter pass available for this kernel (rocprofv3 failed and no committed "
+                                           "pass matches these sources): utilisation not stated"})
+        return r
+    nv, nt = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    sec = kms * 1e-3
+    # GRBM_GUI_ACTIVE counts per XCD (8 of them): cycles the chip was busy in the profiled launch ~ clock x duration
+    n64 = None
+    if fp64 and "SQ_INSTS_VALU_FMA_F64" in c:   # fp64 add / mul / fma counted by class; the rest (moves, integer, compares, max) at 2
+        n64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+        valu_cyc = (nv - nt - n64) * CYC_VALU + n64 * CYC_VALU_F64 + nt * CYC_TRANS
+    else:
+        valu_cyc = ((nv - nt) * (CYC_VALU_F64 if fp64 else CYC_VALU) + nt * CYC_TRANS)
+    valu = valu_cyc / sec / 1e9                     # Gcycle/s of VALU issue actually consumed, whole chip
+    lds = c.get("SQ_LDS_IDX_ACTIVE", 0.0) / sec / 1e9
+    peak_valu, peak_lds = N_SIMD * NOMINAL_CLK_HZ / 1e9, N_CU * NOMINAL_CLK_HZ / 1e9
+    fv, fl = valu / peak_valu, lds / peak_lds
+    traffic = None
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:   # rocprofv3 reports KiB; gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)
+        traffic = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+    if fv >= fl:
+        r.update({"bound": "valu_issue", "achieved": valu, "peak": peak_valu, "unit": "Gcycle/s", "frac": fv})
+    else:
+        r.update({"bound": "lds", "achieved": lds, "peak": peak_lds, "unit": "Gcycle/s", "frac": fl})
+    r.update({"traffic": traffic, "valu_issue_frac": fv, "lds_array_frac": fl,
+              "lds_bank_conflict_share": (c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
+              "wave_wait_share": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
+              "valu_insts_per_launch": nv, "trans_insts_per_launch": nt, "f64_arith_insts_per_launch": n64,
+              "model": "VALU: (%s x non-transcendental + %g x transcendental wave-instructions) / (1024 SIMDs x 2.4 GHz x kernel time)%s; "
+                       "LDS: SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x kernel time); nominal clock, so both are lower bounds of the "
+                       "utilisation at the clock actually sustained" % (("%g" % (CYC_VALU_F64 if fp64 else CYC_VALU)), CYC_TRANS,
+                                                                       (" — fp64 add/mul/fma (SQ_INSTS_VALU_*_F64) at 4 cycles, everything else at 2" if n64 is not None else
+                                                                        " — every VALU op priced as fp64 (upper bound)") if fp64 else "")})
+    return r
+
+
+def roofline_hbm(c, src, kms, F, bpf):
+    achieved = F * bpf / (kms * 1e-3) / 1e9
+    traffic = None
+    if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_over_algorithmic": (traffic / (F * bpf)) if traffic else None, "kernel_ms": kms,
+            "bytes_per_frame": bpf, "counters_from": src,
+            "model": "SURVEY 8(d) streamed model: %d B/frame x %d frames / %.3f ms mean kernel time; the messages live in HBM, "
+                     "so this IS memory traffic (traffic = FETCH_SIZE x2 + WRITE_SIZE of a rocprofv3 pass over the same launch)" % (bpf, F, kms)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--inproc", type=int, default=0, help="drive N GPUs from ONE process (no torch.distributed)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1 << 20, help="frames per GPU per step (config 2: 1M)")
+    ap.add_argument("--frames", type=int, default=1 << 20, help="frames per GPU per step (configs[1], configs[2]: 1M)")
+    ap.add_argument("--c5-frames", type=int, default=32768, help="frames per GPU per step of configs[4] (262144 over 8 GPUs)")
     ap.add_argument("--snr", type=float, default=-2.0)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--matrix", default=os.path.join(ROOT, "data", "H05.txt"))
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per frame (0 = library default)")
-    ap.add_argument("--engine", choices=["auto", "fused", "streamed"], default="auto",
-                    help="BP engine (default auto = fused LDS-resident for H05; streamed = messages in HBM)")
-    ap.add_argument("--algo", choices=["bp", "minsum", "qpadmm"], default="bp")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per frame of the fused BP kernels (0 = library default)")
     ap.add_argument("--alpha", type=float, default=1.95)
     ap.add_argument("--mu", type=float, default=0.5)
-    ap.add_argument("--synthetic", type=int, nargs=4, metavar=("M", "N", "DV", "DC"), default=None,
-                    help="use a seeded (dv,dc)-regular M x N code instead of --matrix (configs[4]: 5000 10000 3 6)")
+    ap.add_argument("--side-steps", type=int, default=3, help="timed steps of every side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the early-exit side measurements")
-    ap.add_argument("--cpu-frames-per-proc", type=int, default=1500)
+    ap.add_argument("--no-extras", action="store_true", help="headline only")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (default: on at N=1)")
+    ap.add_argument("--write-pmc", default=None, help="also store this run's counter passes here (profiles/pmc_rNN.json)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time target of each CPU baseline sample")
+    ap.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-items", default="", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
     import acg_alp_ldpc_amd as A
-    from acg_alp_ldpc_amd._lib import McCfg, check, lib
-    import ctypes as C
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     if not A.device_available():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
-    # one process per GPU.  ACG_BENCH_BACKEND=gloo (+ ranks sharing a GPU) is only for rehearsing the N>1 control
-    # path on a one-GPU box; the driver's runs use nccl (= RCCL) with one GPU per rank.
-    backend = os.environ.get("ACG_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    red_dev = "cuda" if backend == "nccl" else "cpu"
+    if a.pmc_probe:
+        return pmc_probe_child(a)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if a.synthetic:
-        m_, n_, dv_, dc_ = a.synthetic
-        H = A.ParityCheckMatrix(A.regular_ldpc(m_, n_, dv_, dc_, seed=1))
-        a.matrix = "synthetic_%dx%d_(%d,%d)" % (m_, n_, dv_, dc_)
-        cws = np.zeros((1, n_), dtype=np.uint8)     # all-zero codeword (both decoders are symmetric, SURVEY H7)
-    else:
-        H = A.read_pcm(a.matrix)
-        G, ok = H.get_orthogonal()
-        assert ok
-        cws = A.gen_random_codewords(G, 8192, 239239239)
+    rig = Rig(a)
+    T = ctor_table(A, a)
+    H, cws = load_h05(A, a)
     n, E, F = H.n, H.E, a.frames
-    nw = (n + 31) // 32
-    eng = {"auto": A.ENGINE_AUTO, "fused": A.ENGINE_FUSED, "streamed": A.ENGINE_STREAMED}[a.engine]
+    batch = Batch(rig, H, cws, F)
+    ss = max(1, a.side_steps)
 
-    def make(early_exit):
-        if a.algo == "qpadmm":
-            # fixed work for QP-ADMM = eps_stop 0 (the residual test never fires): every frame runs max_iter sweeps
-            return A.QPADMMDecoder(a.alpha, a.mu, a.iters, 1e-5 if early_exit else 0.0, device=local_rank,
-                                   lanes_per_frame=a.lanes)
-        if a.algo == "minsum":
-            return A.MinSumDecoder(a.iters, 0.75, early_exit=early_exit, device=local_rank, lanes_per_frame=a.lanes,
-                                   engine=eng)
-        return A.BeliefPropagationDecoder(a.iters, early_exit=early_exit, device=local_rank, lanes_per_frame=a.lanes,
-                                          engine=eng)
-
-    dec_fixed = make(False)
-    dec_exit = make(True)
-
-    y = torch.empty((F, n), dtype=torch.float32, device="cuda")
-    bits = torch.zeros((F, nw), dtype=torch.int32, device="cuda")
-    okf = torch.zeros(F, dtype=torch.uint8, device="cuda")
-    its = torch.zeros(F, dtype=torch.int32, device="cuda")
-    # a dedicated (non-null) HIP stream: kernels and the timing events are issued on the same stream
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-
-    def gen_noise(snr):
-        h, _ = dec_fixed.handle(H)
-        cfg = McCfg()
-        cfg.frames, cfg.first_frame, cfg.snr, cfg.seed, cfg.noise = F, rank * F, snr, 1, 0
-        cfg.codewords, cfg.n_codewords = cws.ctypes.data, cws.shape[0]
-        check(lib().acg_ldpc_awgn_dev(h, C.byref(cfg), y.data_ptr(), stream.cuda_stream))
-        torch.cuda.synchronize()
-
-    def run(dec, snr, steps, warmup):
-        """-> (seconds for `steps` steps (max over ranks), mean kernel ms on this rank)"""
-        for _ in range(warmup):
-            dec.decode_batch_dev(H, y.data_ptr(), False, F, snr, bits.data_ptr(), okf.data_ptr(), its.data_ptr(),
-                                 stream.cuda_stream)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        barrier()
-        t0 = time.perf_counter()
-        for s in range(steps):
-            ev[s][0].record(stream)   # HIP events on the stream the kernel is launched on
-            dec.decode_batch_dev(H, y.data_ptr(), False, F, snr, bits.data_ptr(), okf.data_ptr(), its.data_ptr(),
-                                 stream.cuda_stream)
-            ev[s][1].record(stream)
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        kms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / steps
-        return dt, kms
-
-    def quality():
-        """FER / mean iterations of the batch currently in (bits, okf, its), all ranks"""
-        idx = (torch.arange(F, device="cuda", dtype=torch.int64) + rank * F) % cws.shape[0]
-        pad = np.zeros((cws.shape[0], nw * 32), dtype=np.uint8)
-        pad[:, :n] = cws
-        cwp = torch.from_numpy(np.packbits(pad, axis=1, bitorder="little").view(np.int32).copy()).cuda()
-        good = (bits == cwp[idx]).all(dim=1) & (okf == 1)  # (QP-ADMM: ok is always 1; a wrong word is counted by the compare)
-        v = torch.stack([good.sum(), okf.sum(), its.sum(), torch.tensor(F, device="cuda")]).to(torch.int64).to(red_dev)
-        if world > 1:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        c, k, i, t = (int(x) for x in v.tolist())
-        return {"fer": (t - c) / t, "undetected": k - c, "mean_iters": i / t, "frames": t}
-
-    # ---- headline: fixed 50 iterations, SNR a.snr --------------------------------------------------------
-    gen_noise(a.snr)
-    dt, kms = run(dec_fixed, a.snr, a.steps, a.warmup)
-    q_fixed = quality()
-    value = world * F * a.steps / dt
-    if a.algo == "qpadmm":
-        sh = H.admm_shape()
-        bpf = admm_bytes_per_frame(n, sh["n_con"], sh["n_var"], a.iters)
-    else:
-        bpf = bp_bytes_per_frame(n, E, a.iters)
-    achieved = F * bpf / (kms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    engine_name = "streamed" if dec_fixed.layout(H)["lanes_per_frame"] == 1 else "fused"
-    if os.path.exists(tpath):
-        try:
-            for tj in json.load(open(tpath)):
-                if (tj.get("frames") == F and tj.get("iters") == a.iters and tj.get("engine") == engine_name
-                        and tj.get("matrix") == os.path.basename(a.matrix) and tj.get("algo") == a.algo):
-                    traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    # The fused engine is bound by VALU issue, not by HBM: price it against that too.  Instruction counts per launch
-    # come from the committed rocprofv3 PMC pass of this exact configuration (they do not change with the clock);
-    # issue cost 2 cycles per wave64 VALU op, 12 per transcendental (tools/microbench/valu_rates.hip), 1024 SIMDs.
-    valu = None
-    try:
-        for pf in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-            if not pf.endswith("_summary.json"):
-                continue
-            pj = json.load(open(os.path.join(ROOT, "profiles", pf)))
-            tj = pj.get("traffic", {})
-            if (tj.get("frames") == F and tj.get("iters") == a.iters and tj.get("engine") == engine_name
-                    and tj.get("matrix") == os.path.basename(a.matrix) and tj.get("algo") == a.algo):
-                pm = pj["pmc_mean_per_launch"]
-                nv, nt = pm["SQ_INSTS_VALU"], pm.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-                clk = pm["GRBM_GUI_ACTIVE"] / 8 / (pj["kernel_stats"][0]["avg_ms"] * 1e-3)
-                busy = ((nv - nt) * 2 + nt * 12) / 1024
-                valu = {"shader_clock_hz": clk, "source": "profiles/" + pf}
-                if a.algo != "qpadmm":  # fp64 VALU ops issue at 4 cycles: the 2/12-cycle pricing only fits the fp32 kernels
-                    valu.update({"issue_cycles_per_simd_per_launch": busy, "frac_of_valu_issue_capacity": busy / (clk * kms * 1e-3)})
-                if "SQ_LDS_IDX_ACTIVE" in pm:  # LDS-array cycles (incl. bank conflicts) summed over the 256 CUs
-                    valu["frac_of_lds_array_cycles"] = pm["SQ_LDS_IDX_ACTIVE"] / 256 / (clk * kms * 1e-3)
-                    valu["lds_bank_conflict_share"] = pm.get("SQ_LDS_BANK_CONFLICT", 0.0) / pm["SQ_LDS_IDX_ACTIVE"]
-    except Exception:
-        valu = None
+    # ---- headline: fixed 50 iterations, SNR a.snr -------------------------------------------------------
+    head = decode_leg(rig, batch, T["bp_fused"], a.snr, a.steps, a.warmup)
+    bpf = bp_bytes_per_frame(n, E, a.iters)
     out = {
-        "metric": "decoded frames/sec (+ FER@SNR) for H05.txt 50-iter BP", "value": value, "unit": "frames/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f64" if a.algo == "qpadmm" else "f32"), "data": "synthetic",
-        "config": {"workload": "%s: %s (%dx%d, E=%d) %s, %d iterations FIXED (no early exit), "
-                               "%d AWGN frames per GPU per step at Es/N0 %.1f dB, inputs/outputs resident in HBM"
-                               % ("configs[4]" if a.synthetic else ("configs[2]" if a.algo == "qpadmm" else "configs[1]"), os.path.basename(a.matrix), H.m, n, E,
-                                  {"bp": "sum-product BP", "minsum": "min-sum(0.75) BP",
-                                   "qpadmm": "QP-ADMM(%g,%g) fp64" % (a.alpha, a.mu)}[a.algo], a.iters, F, a.snr),
-                   "engine": "streamed (messages in HBM)" if dec_fixed.layout(H)["lanes_per_frame"] == 1
-                             else "fused (messages in LDS)",
-                   "frames_per_gpu": F, "snr_db": a.snr, "iters": a.iters, "early_exit": False,
-                   "sharding": "frames [r*F,(r+1)*F) per rank, no collective on the data path",
-                   "layout": dec_fixed.layout(H)},
-        "fer": q_fixed["fer"], "undetected_errors": q_fixed["undetected"], "mean_exit_iter": q_fixed["mean_iters"],
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "model": ("streamed model (SURVEY 8d): %d B/frame x %d frames / %.3f ms mean kernel time; "
-                               % (bpf, F, kms)) +
-                              ("messages live in HBM: this IS the HBM figure" if dec_fixed.layout(H)["lanes_per_frame"] == 1
-                               else "streamed-EQUIVALENT only: messages stay in LDS, so this is NOT HBM utilisation"),
-                     "kernel_ms": kms, "bytes_per_frame": bpf, "valu_issue": valu},
+        "metric": "decoded frames/sec (+ FER@SNR) for H05.txt 50-iter BP", "value": head["value"], "unit": "frames/s",
+        "n_gpus": rig.nshards, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: %s (%dx%d, E=%d) sum-product BP, %d iterations FIXED (no early exit), %d AWGN "
+                               "frames per GPU per step at Es/N0 %.1f dB, inputs/outputs resident in HBM"
+                               % (os.path.basename(a.matrix), H.m, n, E, a.iters, F, a.snr),
+                   "engine": "fused (messages in LDS)", "frames_per_gpu": F, "snr_db": a.snr, "iters": a.iters,
+                   "early_exit": False, "launcher": rig.launcher,
+                   "sharding": "frames [s*F,(s+1)*F) per GPU, no collective on the data path; control plane: %s"
+                               % ("gloo (CPU tensors)" if rig.dist and rig.backend != "nccl" else ("nccl" if rig.dist else "none")),
+                   "layout": head["layout"]},
+        "fer": head["fer"], "undetected_errors": head["undetected_errors"], "mean_exit_iter": head["mean_iters"],
     }
+    single = rig.nshards == 1
 
-    # ---- reference semantics (early exit) at a.snr and +2 dB ---------------------------------------------
+    # ---- counter passes of this run (N = 1 only) --------------------------------------------------------
+    pmc = None
+    if single and not a.no_pmc and not a.no_extras:
+        rig.sync_local()
+        pmc = pmc_collect(a, budget_s=300)
+        if a.write_pmc and "error" not in pmc:
+            json.dump(pmc, open(a.write_pmc, "w"), indent=1)
+    if pmc is None or "error" in (pmc or {}):
+        # fall back to the committed passes, but only if they were taken from exactly these kernel sources
+        err = (pmc or {}).get("error")
+        pmc = None
+        for f in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if f.startswith("pmc_r") and f.endswith(".json"):
+                try:
+                    cand = json.load(open(os.path.join(ROOT, "profiles", f)))
+                except Exception:
+                    continue
+                if cand.get("csrc_sha") == csrc_sha() and cand.get("frames") == F and cand.get("c5_frames") == a.c5_frames:
+                    pmc = cand
+                    pmc["source"] = "committed profiles/%s (same kernel sources: csrc_sha %s)" % (f, cand["csrc_sha"])
+                    break
+        out["pmc_note"] = ("live counter passes unavailable (%s); " % err if err else "") + \
+                          ("using " + pmc["source"] if pmc else "no committed pass matches these kernel sources (stale passes are refused)")
+    c, src = pmc_lookup(pmc, "bp_fused")
+    out["roofline"] = roofline_fused(c, src, head["kernel_ms"], F, bpf)
+
     if not a.no_extras:
+        # ---- reference semantics (early exit) at a.snr and +2 dB ------------------------------------------
         ee = {}
         for snr in (a.snr, 2.0):
-            gen_noise(snr)
-            dte, kmse = run(dec_exit, snr, max(3, a.steps // 2), 1)
-            q = quality()
-            st = max(3, a.steps // 2)
-            bpf_e = (admm_bytes_per_frame(n, sh["n_con"], sh["n_var"], q["mean_iters"]) if a.algo == "qpadmm"
-                     else bp_bytes_per_frame(n, E, q["mean_iters"]))
-            ee["%+.1fdB" % snr] = {"value": world * F * st / dte, "unit": "frames/s", "ms_per_step": dte / st * 1e3,
-                                    "kernel_ms": kmse, "fer": q["fer"], "mean_iters": q["mean_iters"],
-                                    "roofline_frac_streamed_equiv": F * bpf_e / (kmse * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            r = decode_leg(rig, batch, T["bp_exit"], snr, ss, 1)
+            r["streamed_equiv_frac"] = F * bp_bytes_per_frame(n, E, r["mean_iters"]) / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            ee["%+.1fdB" % snr] = r
         out["early_exit"] = ee
-        # north_star's named variant: normalised min-sum (NOT in the reference: parity unpinned, SURVEY D2)
-        if a.algo == "bp" and not a.synthetic:
-            ms = {}
-            for early, tag in ((False, "fixed"), (True, "early_exit")):
-                dms = A.MinSumDecoder(a.iters, 0.75, early_exit=early, device=local_rank, lanes_per_frame=a.lanes, engine=eng)
-                gen_noise(a.snr)
-                dtm, kmsm = run(dms, a.snr, max(3, a.steps // 2), 1)
-                q = quality()
-                st = max(3, a.steps // 2)
-                ms[tag] = {"value": world * F * st / dtm, "unit": "frames/s", "kernel_ms": kmsm, "fer": q["fer"],
-                           "mean_iters": q["mean_iters"], "snr_db": a.snr}
-                dms.close()
-            out["minsum_0.75"] = ms
-            # configs[2]: QP-ADMM(alpha, mu) fp64, 100 sweeps, on the first quarter of the same frames (the run() helper
-            # decodes F frames, so the decoder is driven directly here); eps_stop 0 = every frame runs all sweeps
-            Fq = max(1, F // 4)
-            qa = {}
-            for eps, tag in ((0.0, "fixed"), (1e-5, "residual_exit")):
-                dq = A.QPADMMDecoder(a.alpha, a.mu, 100, eps, device=local_rank)
-                gen_noise(a.snr)
-                st = 3
-                for it_ in range(st + 1):
-                    if it_ == 1:
-                        barrier()
-                        t0 = time.perf_counter()
-                    dq.decode_batch_dev(H, y.data_ptr(), False, Fq, a.snr, bits.data_ptr(), okf.data_ptr(), its.data_ptr(),
-                                        stream.cuda_stream)
-                barrier()
-                dtq = time.perf_counter() - t0
-                if world > 1:
-                    tq = torch.tensor([dtq], dtype=torch.float64, device=red_dev)
-                    dist.all_reduce(tq, op=dist.ReduceOp.MAX)
-                    dtq = float(tq.item())
-                qa[tag] = {"value": world * Fq * st / dtq, "unit": "frames/s", "ms_per_step": dtq / st * 1e3,
-                           "frames_per_gpu": Fq, "mean_sweeps": float(its[:Fq].double().mean().item()), "snr_db": a.snr,
-                           "dtype": "f64", "layout": dq.layout(H)}
-                dq.close()
-            out["qpadmm_%g_%g_100" % (a.alpha, a.mu)] = qa
+        # ---- north_star's named variant: normalised min-sum (NOT in the reference: parity unpinned, SURVEY D2) --
+        out["minsum_0.75"] = {"fixed": decode_leg(rig, batch, T["ms_fused"], a.snr, ss, 1),
+                              "early_exit": decode_leg(rig, batch, T["ms_exit"], a.snr, ss, 1),
+                              "note": "min-sum is not in the reference: parity unpinned"}
+        # ---- the HBM-resident engine: messages [edge][frame] in HBM, one lane per frame ------------------
+        st = {}
+        for key, item in (("sum_product", "bp_streamed"), ("minsum_0.75", "ms_streamed")):
+            r = decode_leg(rig, batch, T[item], a.snr, ss, 1)
+            c, src = pmc_lookup(pmc, item)
+            r["roofline"] = roofline_hbm(c, src, r["kernel_ms"], F, bpf)
+            st[key] = r
+        st["workload"] = "configs[1] on the streamed engine: same frames, 50 iterations fixed, messages in HBM"
+        out["streamed"] = st
+        # ---- configs[2]: QP-ADMM(alpha, mu) fp64, 100 sweeps, 1M frames ----------------------------------
+        sh = H.admm_shape()
+        bpf_q = admm_bytes_per_frame(n, sh["n_con"], sh["n_var"], 100)
+        q_fixed = decode_leg(rig, batch, T["qpadmm"], a.snr, ss, 1)
+        c, src = pmc_lookup(pmc, "qpadmm")
+        q_fixed["roofline"] = roofline_fused(c, src, q_fixed["kernel_ms"], F, bpf_q, fp64=True)
+        q_exit = decode_leg(rig, batch, T["qpadmm_exit"], a.snr, ss, 1)
+        out["configs[2]"] = {"workload": "H05 QP-ADMM(%g, %g) fp64, 100 sweeps, %d frames per GPU per step at %.1f dB"
+                                         % (a.alpha, a.mu, F, a.snr), "dtype": "f64",
+                             "fixed_100_sweeps": q_fixed, "residual_exit_1e-5": q_exit}
+        # ---- Monte-Carlo mode: the metric as SURVEY §8(d) defines it -------------------------------------
+        out["monte_carlo"] = {
+            "definition": "acg_ldpc_mc_run: AWGN generated on the device, decode with the reference's stopping rule, "
+                          "classification against the sent word, D2H of the seven counters; wall time of the calls",
+            "bp50_%+.1fdB" % a.snr: mc_leg(rig, H, cws, T["bp_exit"], a.snr, F, ss),
+            "bp50_+2.0dB": mc_leg(rig, H, cws, T["bp_exit"], 2.0, F, ss),
+            "qpadmm100_%+.1fdB" % a.snr: mc_leg(rig, H, cws, T["qpadmm_exit"], a.snr, F // 4, ss),
+        }
+        # ---- configs[4]: synthetic (3,6)-regular 5000 x 10000, min-sum 50 iterations ---------------------
+        del batch
+        rig.torch.cuda.empty_cache()
+        H5, cw5 = load_c5(A)
+        b5 = Batch(rig, H5, cw5, a.c5_frames)
+        bpf5 = bp_bytes_per_frame(H5.n, H5.E, 50)
+        c5 = {"workload": "configs[4]: synthetic (3,6)-regular %dx%d (E=%d), 50 iterations FIXED, %d frames per GPU per step "
+                          "at +2.0 dB, all-zero codeword" % (H5.m, H5.n, H5.E, a.c5_frames)}
+        for key, item, hbm in (("fused_block_minsum", "c5_block_ms", False), ("fused_block_sum_product", "c5_block_spa", False),
+                               ("streamed_minsum", "c5_streamed_ms", True)):
+            r = decode_leg(rig, b5, T[item], 2.0, ss, 1)
+            c, src = pmc_lookup(pmc, item)
+            if hbm:
+                r["roofline"] = roofline_hbm(c, src, r["kernel_ms"], a.c5_frames, bpf5)
+            elif c or item == "c5_block_ms":
+                r["roofline"] = roofline_fused(c, src, r["kernel_ms"], a.c5_frames, bpf5)
+            c5[key] = r
+        out["configs[4]"] = c5
+        del b5
 
-    # ---- CPU baseline (rank 0, N = 1 only) -------------------------------------------------------------
-    if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(H.dense(), cws, a.snr, a.iters, a.cpu_frames_per_proc)
-    elif world == 1:
+    # ---- CPU baselines (rank 0, N = 1 only) -------------------------------------------------------------
+    if single and not a.no_cpu_baseline:
+        Hd = H.dense()
+        out["cpu_baseline"] = cpu_baseline("bp", Hd, cws, a.snr, a.iters, a.cpu_seconds)
+        out["cpu_baseline_qpadmm"] = cpu_baseline("qpadmm", Hd, cws, a.snr, 100, a.cpu_seconds, a.alpha, a.mu)
+    elif single:
         out["cpu_baseline"] = None
+    if pmc:
+        out["pmc"] = {"source": pmc.get("source"), "csrc_sha": pmc.get("csrc_sha"), "seconds": pmc.get("seconds"),
+                      "passes": [t for t, _ in PMC_PASSES], "items": pmc["items"]}
 
-    if rank == 0:
+    if rig.rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    rig.close()
 
 
 if __name__ == "__main__":

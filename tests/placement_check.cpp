@@ -45,7 +45,42 @@ static int gather_mode(int n_checks) {
     return 0;
 }
 
+// "admm <matrix.txt> <L>": acg::admm_block_placement on a real code, annealed (mode 1) vs quasi-cyclic tuples (mode 2):
+// prints "<qc 0/1> <Z> <tuple>  <annealed: u_reads v_reads v_writes>  <qc: u_reads v_reads v_writes>  <ideal: ...>
+//         <annealed wave costs x4> <qc wave costs x4>" after checking that both placements are valid maps
+static int admm_mode(const char *path, int L) {
+    std::vector<uint8_t> Hd;
+    int m = 0, n = 0;
+    if (!acg::code_read_txt(path, Hd, m, n)) return printf("CANNOT READ\n"), 1;
+    acg::Code c;
+    if (!acg::code_build(c, Hd.data(), m, n)) return printf("CANNOT BUILD\n"), 1;
+    acg::AdmmBlockPlacement P[2];
+    for (int mode = 1; mode <= 2; mode++) {
+        acg::AdmmBlockPlacement &p = P[mode - 1];
+        acg::admm_block_placement(c, L, false, mode, p);
+        // validity: every variable in exactly one thread slot, distinct cells, every group in a distinct slot,
+        // the zero slot / zero cell unused
+        std::vector<int> seen(c.admm.n_var, 0), cells(p.n_cells, 0), slots((size_t) p.n_gpass * L, 0);
+        for (int v : p.var_of_slot)
+            if (v >= 0 && (v >= c.admm.n_var || seen[v]++)) return printf("BAD var_of_slot\n"), 1;
+        for (int v = 0; v < c.admm.n_var; v++) {
+            if (!seen[v]) return printf("VARIABLE WITHOUT SLOT\n"), 1;
+            if (p.cell_of_var[v] < 0 || p.cell_of_var[v] >= p.n_cells || p.cell_of_var[v] == p.zero_cell || cells[p.cell_of_var[v]]++)
+                return printf("BAD cell\n"), 1;
+        }
+        for (int g = 0; g < c.admm.n_grp; g++)
+            if (p.slot_of_grp[g] < 0 || p.slot_of_grp[g] >= p.n_gpass * L || p.slot_of_grp[g] == p.zero_gslot || slots[p.slot_of_grp[g]]++)
+                return printf("BAD slot\n"), 1;
+    }
+    printf("%d %d %d  %ld %ld %ld  %ld %ld %ld  %ld %ld %ld  %d %d %d %d  %d %d %d %d\n", P[1].qc ? 1 : 0, P[1].Z, P[1].tuple, P[0].cyc_u_reads,
+           P[0].cyc_v_reads, P[0].cyc_v_writes, P[1].cyc_u_reads, P[1].cyc_v_reads, P[1].cyc_v_writes, P[1].ideal_u_reads,
+           P[1].ideal_v_reads, P[1].ideal_v_writes, P[0].wave_cost[0], P[0].wave_cost[1], P[0].wave_cost[2], P[0].wave_cost[3],
+           P[1].wave_cost[0], P[1].wave_cost[1], P[1].wave_cost[2], P[1].wave_cost[3]);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 3 && std::string(argv[1]) == "admm") return admm_mode(argv[2], atoi(argv[3]));
     if (argc > 3 && std::string(argv[3]) == "gather") return gather_mode(atoi(argv[1]));
     const int n_items = argc > 1 ? atoi(argv[1]) : 544, rounds = argc > 2 ? atoi(argv[2]) : 2000;
     std::vector<acg::PlacementSet> sets;

@@ -476,6 +476,7 @@ def test_config5_synthetic_regular_code(A, oracle):
     sigma = np.sqrt(A.llr_variance(snr))
     y = 1.0 + sigma * rng.standard_normal((12, 10000))      # all-zero codeword
     ob, ook, oit = oracle.minsum_decode(Hm, y, snr, 50, 0.75, threads=8)
+    ob1, ook1, oit1 = ob, ook, oit
     dec64 = A.MinSumDecoder(50, 0.75, precision=A.PREC_F64)
     bits, ok, iters = dec64.decode_batch(H, y, snr)
     assert dec64.layout(H)["lanes_per_frame"] == 1            # streamed engine chosen automatically
@@ -506,10 +507,10 @@ def test_config5_synthetic_regular_code(A, oracle):
         b1, k1, i1 = ms.decode_batch(H, y, snr)
         b2, k2, i2 = ms.decode_batch(H, y2, -1.6)
         ms.close()
-        same = np.concatenate([(k1 == ook) & (b1 == ob).all(axis=1), (k2 == ook2) & (b2 == ob2).all(axis=1)])
-        same_it = np.concatenate([i1 == oit, i2 == oit2])
+        same = np.concatenate([(k1 == ook1) & (b1 == ob1).all(axis=1), (k2 == ook2) & (b2 == ob2).all(axis=1)])
+        same_it = np.concatenate([i1 == oit1, i2 == oit2])
         assert same.sum() >= 23 and (same & same_it).sum() >= 20, (ee, int(same.sum()), int((same & same_it).sum()))
-    assert ook.all() and not ook2.all() and oit2[ook2 == 1].max() > 30     # the second set really sits at the threshold
+    assert ook1.all() and not ook2.all() and oit2[ook2 == 1].max() > 30     # the second set really sits at the threshold
     dec = A.MinSumDecoder(50, 0.75, early_exit=False)
     r = A.run_experiment(dec, None, H, snr, frames=4096, noise="device", seed=3)
     assert r.total == 4096 and r.pseudo == 0 and r.correct >= 4090, r

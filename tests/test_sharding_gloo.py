@@ -26,11 +26,21 @@ def _oracle_shard(o, Hm, cws, snr, lo, cnt, max_iter):
     return np.array([good.sum(), pseudo.sum(), cnt, ham.sum(), ham[good].sum(), ham[~good].sum(), iters.sum()], np.int64)
 
 
+def _install_oracle_backed_run_experiment(E, o, Hm):
+    """No GPU here: the C-ABI call behind run_experiment is replaced by the oracle decoding exactly the frames the
+    C ABI would have been asked for (global range, reference seeding).  Everything above it — shard ranges, threads,
+    the all_reduce, the merge — is the product's own code."""
+    def fake_run(decoder, codewords, H, snr, frames=None, first_frame=0, noise="host", seed=1):
+        v = _oracle_shard(o, Hm, codewords, snr, int(first_frame), int(frames), decoder)
+        return E.ExperimentResult.from_vector(v)
+    E.run_experiment = fake_run
+
+
 def _worker(rank, world, port, frames, snr, out_path):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from acg_alp_ldpc_amd.experiment import ExperimentResult, shard_range
+    import acg_alp_ldpc_amd.experiment as E
     from oracle.pyoracle import Oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -39,27 +49,32 @@ def _worker(rank, world, port, frames, snr, out_path):
     Hm = o.read_pcm(os.path.join(ROOT, "data", "H.txt"))
     G, _ = o.get_orthogonal(Hm)
     cws = o.gen_codewords(G, 239239239, 97)
-    lo, cnt = shard_range(frames, rank, world)
-    local = _oracle_shard(o, Hm, cws, snr, lo, cnt, 20)
-    v = torch.from_numpy(local.copy())
-    dist.all_reduce(v, op=dist.ReduceOp.SUM)     # merge_exp_results (experiment.h:70-78) across ranks
-    # timing contract of bench.py: barrier, then MAX over ranks
+    _install_oracle_backed_run_experiment(E, o, Hm)
+    # the product's N>1 path: this rank's contiguous global range + the SUM of the seven counters over gloo
+    local, total = E.run_experiment_sharded(20, cws, None, snr, frames, rank=rank, world=world, noise="host")
+    lo, cnt = E.shard_range(frames, rank, world)
+    assert local.total == cnt
+    # timing contract of bench.py: barrier, then MAX over ranks (CPU tensors on gloo — the control plane of bench.py)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.barrier()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        r = ExperimentResult.from_vector(v.numpy())
-        np.save(out_path, np.concatenate([r.as_vector(), [int(t.item())]]))
+        np.save(out_path, np.concatenate([total.as_vector(), [int(t.item())]]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("frames", [301])
-def test_two_rank_shards_equal_single_process(tmp_path, frames):
+def _setup():
     from oracle.pyoracle import Oracle
     o = Oracle()
     Hm = o.read_pcm(os.path.join(ROOT, "data", "H.txt"))
     G, _ = o.get_orthogonal(Hm)
-    cws = o.gen_codewords(G, 239239239, 97)
+    return o, Hm, o.gen_codewords(G, 239239239, 97)
+
+
+@pytest.mark.parametrize("frames", [301])
+def test_two_rank_shards_equal_single_process(tmp_path, frames):
+    """run_experiment_sharded under 2 gloo ranks == one process over all frames (counters incl. sum of exit iterations)"""
+    o, Hm, cws = _setup()
     snr = 0.5
     single = _oracle_shard(o, Hm, cws, snr, 0, frames, 20)
     out = str(tmp_path / "r.npy")
@@ -71,32 +86,35 @@ def test_two_rank_shards_equal_single_process(tmp_path, frames):
     assert single[2] == frames and single[3] == single[4] + single[5]
 
 
-def test_run_experiment_sharded_uses_global_frame_index():
-    """host-side logic of run_experiment_sharded without a device: the shard passed to the C ABI is the
-    contiguous global range and the counters add up (decoder stubbed)."""
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_inproc_shards_equal_single_process(world):
+    """run_experiment_inproc (one process, one host thread per device, no torch.distributed): same merged counters as
+    N = 1 for any device count, each shard asked for its contiguous global range"""
     import acg_alp_ldpc_amd.experiment as E
-    calls = []
-
-    def fake_run(decoder, codewords, H, snr, frames=None, first_frame=0, noise="host", seed=1):
-        calls.append((first_frame, frames, seed, noise))
-        return E.ExperimentResult(correct=frames - 1, pseudo=0, total=frames, sum_hamming=3 * frames,
-                                  sum_hamming_ok=3 * (frames - 1), sum_hamming_wrong=3, sum_iters=2 * frames)
-
+    o, Hm, cws = _setup()
+    frames, snr = 203, 0.5
+    single = _oracle_shard(o, Hm, cws, snr, 0, frames, 20)
     old = E.run_experiment
-    E.run_experiment = fake_run
+    _install_oracle_backed_run_experiment(E, o, Hm)
     try:
-        tot = None
-        for r in range(3):
-            local, _ = E.run_experiment_sharded(None, None, None, 1.0, 1000, rank=r, world=1 if False else 1)
-            break
-        parts = []
-        for r in range(3):
-            lo, cnt = E.shard_range(1000, r, 3)
-            parts.append(fake_run(None, None, None, 1.0, frames=cnt, first_frame=lo, noise="device", seed=9))
-        tot = parts[0]
-        for p in parts[1:]:
-            E.merge_exp_results(tot, p)
+        made = []
+        locals_, total = E.run_experiment_inproc(lambda dev: made.append(dev) or 20, cws, None, snr, frames,
+                                                 devices=range(world), noise="host")
     finally:
         E.run_experiment = old
-    assert tot.total == 1000 and tot.correct == 997 and tot.sum_iters == 2000
-    assert [c[0] for c in calls[1:]] == [0, 333, 666]
+    assert sorted(made) == list(range(world))
+    assert (total.as_vector() == single).all(), (total, single)
+    assert [r.total for r in locals_] == [E.shard_range(frames, g, world)[1] for g in range(world)]
+    assert sum(r.total for r in locals_) == frames
+
+
+def test_shard_ranges_partition_the_batch():
+    from acg_alp_ldpc_amd.experiment import shard_range
+    for frames in (0, 1, 7, 1000, (1 << 23) + 5):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                lo, cnt = shard_range(frames, r, world)
+                assert lo == nxt and cnt >= 0
+                nxt = lo + cnt
+            assert nxt == frames
