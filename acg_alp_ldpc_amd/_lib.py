@@ -22,7 +22,7 @@ class Params(C.Structure):
     _fields_ = [("algo", C.c_int32), ("max_iter", C.c_int32), ("alpha", C.c_double), ("mu", C.c_double),
                 ("eps_stop", C.c_double), ("ms_scale", C.c_double), ("early_exit", C.c_int32),
                 ("precision", C.c_int32), ("device", C.c_int32), ("lanes_per_frame", C.c_int32),
-                ("engine", C.c_int32), ("reserved", C.c_int32)]
+                ("engine", C.c_int32), ("fast_setup", C.c_int32)]
 
 
 class McCfg(C.Structure):

@@ -680,9 +680,9 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
         while (it < a.max_iter) {
             // Constants the compiler must not see through: everything derived from the register-resident tables
             // (addresses, +-1 patterns) would otherwise be hoisted out of the sweep loop into ~5 registers per entry.
-            uint32_t k80, k1, k2, k3, lds0, one_hi, mlw_o = mlw_pk, gen_o = gen_pk;
-            asm volatile("s_mov_b32 %0, 0x80000000\n\ts_mov_b32 %1, 1\n\ts_mov_b32 %2, 2\n\ts_mov_b32 %3, 3\n\ts_mov_b32 %4, 0"
-                         : "=s"(k80), "=s"(k1), "=s"(k2), "=s"(k3), "=s"(lds0));
+            uint32_t k80, k1, k2, lds0, one_hi, mlw_o = mlw_pk, gen_o = gen_pk;
+            asm volatile("s_mov_b32 %0, 0x80000000\n\ts_mov_b32 %1, 1\n\ts_mov_b32 %2, 2\n\ts_mov_b32 %3, 0"
+                         : "=s"(k80), "=s"(k1), "=s"(k2), "=s"(lds0));
             if (sizeof(T) == 8) asm volatile("v_mov_b32 %0, 0x3ff00000" : "=v"(one_hi));  // in a VGPR: (x & k80) | one_hi is one v_and_or_b32
             else asm volatile("v_mov_b32 %0, 1.0" : "=v"(one_hi));
             asm volatile("" : "+s"(mlw_o), "+s"(gen_o));
@@ -705,7 +705,8 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                             B = X::fma(pm1(e), ux, B);
                             B = X::fma(pm1(e << k1), uy, B);
                             B = X::fma(pm1(e << k2), uz, B);
-                            B = X::fma(pm1(e << k3), uw, B);
+                            B = B + uw;  // row 3 (x_i + x_j + x_h <= 2, qp_admm.h:52-57) has coefficient +1 for every member;
+                                         // one- and two-variable checks have no such row and keep u = 0 there
                         }
                     for (int k = ADMM_VK; k < ml; ++k) {  // lists longer than the register file holds
                         const uint32_t e = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
@@ -714,7 +715,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                         B = X::fma(pm1(e), ux, B);
                         B = X::fma(pm1(e << k1), uy, B);
                         B = X::fma(pm1(e << k2), uz, B);
-                        B = X::fma(pm1(e << k3), uw, B);
+                        B = B + uw;
                     }
                     T v = B * inv[p];
                     v = (v < (T) 0) ? (T) 0 : v;  // std::max(v, 0.0)
@@ -820,17 +821,6 @@ static const void *admm_kernel_ptr(int f32, int L, bool mc, bool reg) {
     return admm_ptr<double, 16, 0>(mc);
 }
 
-// ACG_ADMM_PLACEMENT_DEBUG=1: LDS cycles (sum over sets of the busiest bank) vs the conflict-free count
-static void placement_report(const char *what, std::vector<int> &pos, const int n_pos, const std::vector<PlacementSet> &sets) {
-    if (!getenv("ACG_ADMM_PLACEMENT_DEBUG")) return;
-    std::vector<long> mx;
-    std::vector<int> copy = pos;
-    placement_optimise(copy, n_pos, sets, 0, &mx);
-    long cyc = 0;
-    for (long m : mx) cyc += m;
-    fprintf(stderr, "[acg_ldpc] placement %s: %zu sets, %ld LDS cycles (conflict-free %zu)\n", what, sets.size(), cyc, sets.size());
-}
-
 template <typename T, bool EE>
 static const void *admm_block_ptr_t(int passes) {
     if (passes <= 2) return (const void *) admm_block_kernel<T, EE, 2>;
@@ -880,7 +870,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
             const int passes = std::max(std::max(gp, vp), 2);
             if (passes > ADMM_BP) continue;
             const size_t ts_ = (p.precision == ACG_LDPC_PREC_F32) ? 4 : 8;
-            const size_t lds = (size_t) (4 * gp * cand + A.n_var + 4) * ts_ + 64;
+            const size_t lds = (size_t) (4 * gp * cand + vp * cand + 4) * ts_ + 64;
             const int by_lds = (int) ((160 * 1024) / lds);
             const int by_reg = ((ADMM_OCC - passes + (ts_ == 4 ? ADMM_OCC_F32 : 0)) * 4) / (cand / 64);
             double score = (double) std::min(by_lds, by_reg) / passes;
@@ -938,24 +928,46 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
             grp_mem[(size_t) k * t.G_pad + g] = (uint32_t) A.grp_var[(size_t) g * 3 + wpos] | ((uint32_t) wpos << 24);
         }
     }
-    // variables sorted by list length (descending) so a pass has a uniform trip count
-    std::vector<int> vorder(A.n_var);
-    for (int i = 0; i < A.n_var; i++) vorder[i] = i;
+    // thread slot -> variable.  Wavefront kernels: variables sorted by list length (descending) so a pass has a uniform
+    // trip count.  Workgroup-per-frame kernel: the three maps (variable -> thread slot, group -> U slot, variable ->
+    // V cell) come from admm_block_placement (code.cpp), which places them against LDS bank conflicts.
     auto llen = [&](int i) { return A.var_ptr[i + 1] - A.var_ptr[i]; };
-    std::stable_sort(vorder.begin(), vorder.end(), [&](int x, int y) { return llen(x) > llen(y); });
+    AdmmBlockPlacement P;
     std::vector<int32_t> var_of_slot((size_t) t.n_vpass * L, -1), v_maxlist(t.n_vpass), v_list_off(t.n_vpass);
+    if (d->blockmode) {
+        // ACG_ADMM_NO_PLACEMENT / ACG_ADMM_NO_QC: developer A/B only
+        const int mode = (getenv("ACG_ADMM_NO_PLACEMENT") || p.fast_setup) ? 0 : (getenv("ACG_ADMM_NO_QC") ? 1 : 2);
+        admm_block_placement(c, L, d->f32 != 0, mode, P);
+        if (getenv("ACG_ADMM_PLACEMENT_DEBUG"))
+            fprintf(stderr, "[acg_ldpc] QP-ADMM placement (%s%s): modelled LDS cycles per frame-sweep: U-row reads %ld (conflict-free %ld), "
+                            "V reads %ld (%ld), V writes %ld (%ld); v-update trips per wavefront %d %d %d %d\n",
+                    P.qc ? "quasi-cyclic tuples, Z = " : (mode ? "annealed" : "none"), P.qc ? std::to_string(P.Z).c_str() : "", P.cyc_u_reads,
+                    P.ideal_u_reads, P.cyc_v_reads, P.ideal_v_reads, P.cyc_v_writes, P.ideal_v_writes, P.wave_cost[0], P.wave_cost[1],
+                    P.wave_cost[2], P.wave_cost[3]);
+        for (size_t sidx = 0; sidx < var_of_slot.size(); sidx++) var_of_slot[sidx] = P.var_of_slot[sidx];
+        t.zero_gslot = P.zero_gslot;
+        t.V_pad = (P.n_cells + 3) & ~3;
+    } else {
+        std::vector<int> vorder(A.n_var);
+        for (int i = 0; i < A.n_var; i++) vorder[i] = i;
+        std::stable_sort(vorder.begin(), vorder.end(), [&](int x, int y) { return llen(x) > llen(y); });
+        for (int sidx = 0; sidx < A.n_var; sidx++) var_of_slot[sidx] = vorder[sidx];
+    }
     int off = 0;
     for (int p_ = 0; p_ < t.n_vpass; p_++) {
-        v_maxlist[p_] = llen(vorder[(size_t) p_ * L]);
+        int ml = 0;
+        for (int l = 0; l < L; l++)
+            if (var_of_slot[(size_t) p_ * L + l] >= 0) ml = std::max(ml, llen(var_of_slot[(size_t) p_ * L + l]));
+        v_maxlist[p_] = ml;
         v_list_off[p_] = off;
-        off += v_maxlist[p_] * L;
+        off += ml * L;
     }
-    std::vector<uint32_t> v_list((size_t) std::max(off, 1), (uint32_t) t.zero_gslot);  // type 0, wpos 0 -> adds 0
+    std::vector<uint32_t> v_list((size_t) std::max(off, 1), (uint32_t) A.n_grp);  // padding: slot n_grp of the wavefront kernels, type 0, wpos 0 -> adds 0
     std::vector<double> inv64((size_t) t.n_vpass * L, 0.0);
-    for (int s = 0; s < A.n_var; s++) {
-        const int i = vorder[s];
-        const int p_ = s / L, l = s % L;
-        var_of_slot[s] = i;
+    for (int sidx = 0; sidx < t.n_vpass * L; sidx++) {
+        const int i = var_of_slot[sidx];
+        if (i < 0) continue;
+        const int p_ = sidx / L, l = sidx % L;
         for (int k = 0; k < llen(i); k++) {
             const int ent = A.var_grp[A.var_ptr[i] + k];
             const int g = ent >> 2, wpos = ent & 3;
@@ -963,7 +975,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
                 (uint32_t) g | ((uint32_t) wpos << 20) | ((uint32_t) A.grp_type[g] << 22);
         }
         const double Acoef = (p.mu * A.e[i] - p.alpha) / 2;  // qp_admm.h:125
-        inv64[s] = -1.0 / (2 * Acoef);                        // qp_admm.h:126
+        inv64[sidx] = -1.0 / (2 * Acoef);                     // qp_admm.h:126
     }
     bool ok = true;
     if (d->blockmode) {
@@ -979,79 +991,9 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
             admm_device_destroy(d);
             return nullptr;
         }
-        // slots: three-variable checks first, then the one- and two-variable ones (their wavefronts run the GENERIC
-        // instance of admm_group_update), then padding; slot n_grp is the all-zero slot list padding points to
-        std::vector<int> slot_of(A.n_grp), grp_of(t.G_pad, -1);
-        int n3 = 0;
-        {
-            int sl = 0;
-            for (int pass = 0; pass < 2; pass++) {
-                for (int g = 0; g < A.n_grp; g++)
-                    if ((A.grp_type[g] == 3) == (pass == 0)) slot_of[g] = sl++;
-                if (pass == 0) n3 = sl;
-            }
-        }
-        const bool tune = getenv("ACG_ADMM_NO_PLACEMENT") == nullptr;  // developer A/B only
-        if (tune && n3 > 1) {
-            // v-update: lanes [32h, 32h+32) of (pass, wavefront) read entry k of their variables: ds_read_b64/_b32, bank = slot mod 32
-            std::vector<int> item_of_grp(A.n_grp, -1), pos3;
-            for (int g = 0; g < A.n_grp; g++)
-                if (A.grp_type[g] == 3) {
-                    item_of_grp[g] = (int) pos3.size();
-                    pos3.push_back(slot_of[g]);
-                }
-            std::vector<PlacementSet> sets;
-            for (int p_ = 0; p_ < t.n_vpass; p_++)
-                for (int h = 0; h < L / 32; h++)
-                    for (int k = 0; k < v_maxlist[p_]; k++) {
-                        PlacementSet ps;
-                        ps.modulus = 32;
-                        for (int l = 32 * h; l < 32 * h + 32; l++) {
-                            const int sidx = p_ * L + l;
-                            if (sidx >= A.n_var) continue;
-                            const int i = vorder[sidx];
-                            if (k >= llen(i)) continue;
-                            const int g = A.var_grp[A.var_ptr[i] + k] >> 2;
-                            if (item_of_grp[g] >= 0) ps.items.push_back(item_of_grp[g]);
-                        }
-                        if (ps.items.size() > 1) sets.push_back(std::move(ps));
-                    }
-            placement_report("U slots before", pos3, n3, sets);
-            placement_optimise(pos3, n3, sets, 800);
-            placement_report("U slots after", pos3, n3, sets);
-            for (int g = 0; g < A.n_grp; g++)
-                if (item_of_grp[g] >= 0) slot_of[g] = pos3[item_of_grp[g]];
-        }
+        const std::vector<int> &slot_of = P.slot_of_grp, &cell_of = P.cell_of_var;
+        std::vector<int> grp_of(t.G_pad, -1);
         for (int g = 0; g < A.n_grp; g++) grp_of[slot_of[g]] = g;
-        // variable -> V cell
-        std::vector<int> cell_of(A.n_var);
-        for (int i = 0; i < A.n_var; i++) cell_of[i] = i;
-        if (tune && A.n_var > 1) {
-            std::vector<PlacementSet> sets;
-            // row phase: lanes [32h, 32h+32) of a group pass read member k of their groups: bank = cell mod 32
-            for (int base = 0; base < t.G_pad; base += 32)
-                for (int k = 0; k < 3; k++) {
-                    PlacementSet ps;
-                    ps.modulus = 32;
-                    for (int sl = base; sl < base + 32; sl++) {
-                        const int g = grp_of[sl];
-                        if (g >= 0 && k < A.grp_type[g]) ps.items.push_back((int) (grp_mem[(size_t) k * t.G_pad + g] & 0xFFFFFFu));
-                    }
-                    if (ps.items.size() > 1) sets.push_back(std::move(ps));
-                }
-            // v-update: each lane stores its variable: ds_write_b64 is served 16 lanes at a time (16 bank pairs),
-            // ds_write_b32 32 lanes at a time
-            const int wl = d->f32 ? 32 : 16;
-            for (int base = 0; base < A.n_var; base += wl) {
-                PlacementSet ps;
-                ps.modulus = wl;
-                for (int sidx = base; sidx < std::min(base + wl, A.n_var); sidx++) ps.items.push_back(vorder[sidx]);
-                if (ps.items.size() > 1) sets.push_back(std::move(ps));
-            }
-            placement_report("V cells before", cell_of, A.n_var, sets);
-            placement_optimise(cell_of, A.n_var, sets, 800);
-            placement_report("V cells after", cell_of, A.n_var, sets);
-        }
         std::vector<uint32_t> blk_mem((size_t) 3 * t.G_pad, 0);
         std::vector<uint8_t> type_slot((size_t) t.G_pad, 0), blk_generic((size_t) t.n_gpass * 4, 0);
         for (int sl = 0; sl < t.G_pad; sl++) {
@@ -1062,37 +1004,45 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
             bool row_used[4] = {false, false, false, false};
             for (int k = 0; k < ty; k++) row_used[grp_mem[(size_t) k * t.G_pad + g] >> 24] = true;
             for (int k = 0; k < 3; k++) {
-                uint32_t vid = (uint32_t) A.n_var, row = 0;  // absent member: the zero cell ...
+                uint32_t cell = (uint32_t) P.zero_cell, row = 0;  // absent member: the zero cell ...
                 if (k < ty) {
                     const uint32_t e = grp_mem[(size_t) k * t.G_pad + g];
-                    vid = e & 0xFFFFFFu;
+                    cell = (uint32_t) cell_of[e & 0xFFFFFFu];
                     row = e >> 24;
                 } else {  // ... and a row of this group that no member owns (it stays zero)
                     while (row_used[row]) row++;
                     row_used[row] = true;
                 }
-                const uint32_t cell = vid < (uint32_t) A.n_var ? (uint32_t) cell_of[vid] : vid;
                 blk_mem[(size_t) k * t.G_pad + sl] = (cell * ts) | (u_addr(sl, (int) row) << 16);
             }
         }
-        std::vector<uint32_t> blk_list(v_list.size(), u_addr(t.zero_gslot, 0));  // padding: the all-zero slot, coefficients +1
+        std::vector<uint32_t> blk_list(v_list.size(), u_addr(t.zero_gslot, 0));  // padding: an all-zero slot, coefficients +1
         std::vector<int32_t> blk_mlw((size_t) t.n_vpass * 4, 0), blk_cell((size_t) t.n_vpass * L, -1);
         bool list_ok = true;
-        for (int s = 0; s < A.n_var; s++) {
-            const int i = vorder[s];
-            const int p_ = s / L, l = s % L;
-            blk_cell[s] = cell_of[i];
-            blk_mlw[(size_t) p_ * 4 + l / 64] = std::max(blk_mlw[(size_t) p_ * 4 + l / 64], llen(i));
-            list_ok = list_ok && llen(i) <= 255;
-            for (int k = 0; k < llen(i); k++) {
-                const int ent = A.var_grp[A.var_ptr[i] + k];
-                const int g = ent >> 2, wpos = ent & 3, ty = A.grp_type[g];
-                uint32_t flags = 0;
-                for (int row = 0; row < 4; row++) {
-                    const bool plus = (ty == 3 && row == 3) || (row == wpos);
-                    if (!plus) flags |= 0x80000000u >> row;
+        for (int sidx = 0; sidx < t.n_vpass * L; sidx++) {
+            const int i = var_of_slot[sidx];
+            const int p_ = sidx / L, l = sidx % L;
+            const int len = i >= 0 ? llen(i) : 0;
+            if (i >= 0) {
+                blk_cell[sidx] = cell_of[i];
+                blk_mlw[(size_t) p_ * 4 + l / 64] = std::max(blk_mlw[(size_t) p_ * 4 + l / 64], len);
+                list_ok = list_ok && len <= 255;
+            }
+            for (int k = 0; k < v_maxlist[p_]; k++) {
+                uint32_t &dst = blk_list[(size_t) v_list_off[p_] + (size_t) k * L + l];
+                if (k < len) {
+                    const int ent = A.var_grp[A.var_ptr[i] + k];
+                    const int g = ent >> 2, wpos = ent & 3, ty = A.grp_type[g];
+                    uint32_t flags = 0;
+                    for (int row = 0; row < 4; row++) {
+                        const bool plus = (ty == 3 && row == 3) || (row == wpos);
+                        if (!plus) flags |= 0x80000000u >> row;
+                    }
+                    dst = u_addr(slot_of[g], 0) | flags;
+                } else if (k < P.max_list) {
+                    const int pad = P.pad_gslot[(size_t) sidx * P.max_list + k];  // an all-zero slot in a bank nobody else reads
+                    dst = u_addr(pad >= 0 ? pad : t.zero_gslot, 0);
                 }
-                blk_list[(size_t) v_list_off[p_] + (size_t) k * L + l] = u_addr(slot_of[g], 0) | flags;
             }
         }
         if (!list_ok) {

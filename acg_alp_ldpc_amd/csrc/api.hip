@@ -34,6 +34,8 @@ const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, 
 const void *bp_kernel_ptr_dbg(int f64, int L);
 const void *bp_block_kernel_ptr_dbg(int f64);
 const void *bp_streamed_ptr(int algo, int f64);
+const void *bp_streamed_ring_ptr(int algo);
+hipError_t bp_streamed_ring_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid, hipStream_t s);
 hipError_t bp_streamed_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid,
                               int block, hipStream_t s);
 hipError_t classify_launch(const float *y, const uint32_t *bits, const uint8_t *ok, const int32_t *iters, int64_t frames,
@@ -98,6 +100,7 @@ struct acg_ldpc_decoder {
     bool streamed = false;
     StreamTables stab{};
     const void *skernel = nullptr;
+    const void *sring = nullptr;  // LDS-DMA ring variant (fp32), null = not available for this code
     uint32_t *sws = nullptr;
     int sgrid = 0;
     // ADMM
@@ -244,14 +247,80 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
     UP32S(c.row_ptr, row_ptr)
     UP32S(c.col_ptr, col_ptr)
     UP32S(c.col_edge, col_edge)
-#undef UP32S
     t.m = c.m;
     t.n = c.n;
     t.E = c.E;
     t.nwords = (c.n + 31) / 32;
     const size_t ts = d->f64 ? 8 : 4;
-    // per wavefront: M[E][64] + LLR[n][64] (T) + HB[nwords][64] (u32)
-    t.ws_words_per_wave = (int64_t) (((size_t) (c.E + c.n) * 64 * ts + (size_t) t.nwords * 64 * 4 + 255) / 256 * 64);
+    // LDS-DMA ring engine (fp32, node degrees that fit a ring slot): cut the sweeps into tasks
+    size_t hb_bytes = (size_t) t.nwords * 64 * 4;  // HB[nwords][64] (u32)
+    if (!d->f64 && c.max_cdeg <= RING_SLOT_LINES && c.max_vdeg <= RING_VAR_EDGE_LINES && getenv("ACG_STREAM_NO_RING") == nullptr) {
+        struct Task { int first, cnt, base, lines; };
+        std::vector<Task> ct, vt;
+        for (int i = 0; i < c.m;) {
+            Task k{i, 0, c.row_ptr[i], 0};
+            while (i < c.m && k.cnt < 16 && k.lines + (c.row_ptr[i + 1] - c.row_ptr[i]) <= RING_SLOT_LINES) {
+                k.lines += c.row_ptr[i + 1] - c.row_ptr[i];
+                k.cnt++;
+                i++;
+            }
+            ct.push_back(k);
+        }
+        for (int v = 0; v < c.n;) {
+            Task k{v, 0, c.col_ptr[v], 0};
+            while (v < c.n && k.cnt < 4 && k.lines + (c.col_ptr[v + 1] - c.col_ptr[v]) <= RING_VAR_EDGE_LINES) {
+                k.lines += c.col_ptr[v + 1] - c.col_ptr[v];
+                k.cnt++;
+                v++;
+            }
+            vt.push_back(k);
+        }
+        // vector-memory operations a task certainly issues: loads (one LDS-DMA instruction per four lines, + the LLR lines of
+        // a variable task) and message stores (one per line); the hard-decision byte of a variable task is predicated and
+        // therefore not counted.  wait(i) for the i-th task of a wavefront: see bp_streamed_ring_kernel.
+        auto pack = [&](const std::vector<Task> &tk, bool var) {
+            std::vector<int32_t> out(4 * std::max<size_t>(tk.size(), 1), 0);
+            for (int w = 0; w < RING_WAVES; w++) {
+                std::vector<int> seq;
+                for (int i = w; i < (int) tk.size(); i += RING_WAVES) seq.push_back(i);
+                auto opsL = [&](int i) { return (tk[seq[i]].lines + 3) / 4 + (var ? 1 : 0); };
+                auto opsS = [&](int i) { return tk[seq[i]].lines; };
+                for (int i = 0; i < (int) seq.size(); i++) {
+                    int wl = 0, wsn = 0;
+                    for (int k = i + 1; k <= std::min<int>(i + RING_SLOTS - 1, (int) seq.size() - 1); k++) wl += opsL(k);
+                    for (int j = std::max(0, i - RING_SLOTS + 1); j <= i - 1; j++) wsn += opsS(j);
+                    const Task &k = tk[seq[i]];
+                    out[4 * seq[i] + 0] = k.first;
+                    out[4 * seq[i] + 1] = k.cnt;
+                    out[4 * seq[i] + 2] = k.base;
+                    out[4 * seq[i] + 3] = k.lines | (std::min(wl + wsn, 63) << 8) | (std::min(wl, 63) << 16);
+                }
+            }
+            return out;
+        };
+        std::vector<int32_t> hct = pack(ct, false), hvt = pack(vt, true), hvw(std::max(t.nwords, 1), 0);
+        {
+            size_t ti = 0;
+            for (int k = 0; k < t.nwords; k++) {
+                while (ti + 1 < vt.size() && vt[ti].first + vt[ti].cnt <= 32 * k) ti++;
+                hvw[k] = (int32_t) ti;
+            }
+        }
+        std::vector<int32_t> ce = c.col_edge;
+        ce.resize(ce.size() + 4, 0);  // the gather reads its edge ids four at a time
+        UP32S(hct, ctask)
+        UP32S(hvt, vtask)
+        UP32S(hvw, vtask_of_word)
+        UP32S(ce, col_edge)
+        t.n_ctask = (int32_t) ct.size();
+        t.n_vtask = (int32_t) vt.size();
+        d->sring = bp_streamed_ring_ptr((d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0);
+        HIP_OK(hipFuncSetAttribute(d->sring, hipFuncAttributeMaxDynamicSharedMemorySize, RING_WAVES * RING_SLOTS * RING_SLOT_LINES * 256));
+        hb_bytes = std::max(hb_bytes, (size_t) vt.size() * 64);  // ring engine: one byte per (variable task, frame)
+    }
+#undef UP32S
+    // per workgroup: M[E][64] + LLR[n][64] (T) + hard decisions
+    t.ws_words_per_wave = (int64_t) (((size_t) (c.E + c.n) * 64 * ts + hb_bytes + 255) / 256 * 64);
     d->block = 256;
     d->frames_per_block = 64;  // one 64-frame tile per workgroup at a time
     const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
@@ -260,6 +329,10 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
     // each resident workgroup owns one slab: M[E][64] + LLR[n][64] + HB[nwords][64]
     d->sgrid = 2 * d->cu_count;
     const size_t ws_bytes = (size_t) d->sgrid * (size_t) t.ws_words_per_wave * 4;
+    if (t.ws_words_per_wave < (int64_t) (c.E + c.n) * 64) {  // the kernels index the slab without further checks
+        set_error("internal: streamed-engine slab size not set");
+        return 11;
+    }
     HIP_OK(hipMalloc((void **) &d->sws, ws_bytes));
     d->grid_cap[0] = d->grid_cap[1] = d->sgrid;
     return 0;
@@ -597,7 +670,12 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         while (W < 8 && tiles * W < 8 * (int64_t) d->cu_count) W <<= 1;
         const int per_cu = (W <= 4) ? 2 : 1;
         int grid = (int) std::min<int64_t>(tiles, (int64_t) per_cu * d->cu_count);
-        HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
+        if (d->sring && !a.dbg_c2v && !a.dbg_v2c) {
+            grid = (int) std::min<int64_t>(tiles, 2 * (int64_t) d->cu_count);  // 64 KiB of ring per workgroup: two per CU
+            HIP_OK(bp_streamed_ring_launch(d->sring, d->stab, a, d->sws, grid, s));
+        } else {
+            HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
+        }
     } else {
         int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
         const int mc = a.mc ? 1 : 0;

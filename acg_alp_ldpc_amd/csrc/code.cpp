@@ -5,10 +5,13 @@
 #include "ldpc_internal.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 
 namespace acg {
@@ -601,7 +604,7 @@ void admm_model_cycles(const Code &c, AdmmBlockPlacement &P, bool f32) {
                     for (int l = 64 * w + 32 * h; l < std::min(L, 64 * w + 32 * h + 32); l++) {
                         const int i = P.var_of_slot[(size_t) p * L + l];
                         if (i >= 0 && k < admm_llen(A, i)) addrs.push_back(P.slot_of_grp[A.var_grp[A.var_ptr[i] + k] >> 2]);
-                        else addrs.push_back(P.zero_gslot);  // padding entries read the all-zero slot
+                        else addrs.push_back(P.pad_gslot[((size_t) p * L + l) * P.max_list + k]);  // padding entries read an all-zero slot
                     }
                     if (addrs.empty()) continue;
                     P.cyc_u_reads += cycles_of(addrs, 32);
@@ -635,6 +638,47 @@ void admm_model_cycles(const Code &c, AdmmBlockPlacement &P, bool f32) {
         P.cyc_v_writes += cycles_of(addrs, wl);
         P.ideal_v_writes += 1;
     }
+}
+
+// Padding reads (see AdmmBlockPlacement::pad_gslot).  spread: give every padded lane an unoccupied (all-zero) slot whose
+// bank no real read of its 32-lane service group uses at that entry, so that padding never adds an LDS cycle.
+void admm_assign_pads(const Code &c, AdmmBlockPlacement &P, bool spread) {
+    const AdmmLayout &A = c.admm;
+    const int L = P.L;
+    P.max_list = 1;
+    for (int i = 0; i < A.n_var; i++) P.max_list = std::max(P.max_list, admm_llen(A, i));
+    P.pad_gslot.assign((size_t) P.n_vpass * L * P.max_list, -1);
+    std::vector<std::vector<int>> free_of_bank(32);
+    if (spread) {
+        std::vector<char> used((size_t) P.n_gpass * L, 0);
+        for (int g = 0; g < A.n_grp; g++) used[P.slot_of_grp[g]] = 1;
+        for (int sl = 0; sl < P.n_gpass * L; sl++)
+            if (!used[sl]) free_of_bank[sl % 32].push_back(sl);
+    }
+    for (int p = 0; p < P.n_vpass; p++)
+        for (int base = 0; base < L; base += 32)
+            for (int k = 0; k < P.max_list; k++) {
+                bool bank_used[32] = {};
+                for (int l = base; l < std::min(L, base + 32); l++) {
+                    const int i = P.var_of_slot[(size_t) p * L + l];
+                    if (i >= 0 && k < admm_llen(A, i)) bank_used[P.slot_of_grp[A.var_grp[A.var_ptr[i] + k] >> 2] % 32] = true;
+                }
+                for (int l = base; l < std::min(L, base + 32); l++) {
+                    const int i = P.var_of_slot[(size_t) p * L + l];
+                    if (i >= 0 && k < admm_llen(A, i)) continue;
+                    int pick = P.zero_gslot;
+                    if (spread) {
+                        // all padded lanes of the service group may share ONE address (a broadcast costs nothing extra):
+                        // the first free bank that owns an unoccupied slot
+                        for (int b = 0; b < 32; b++)
+                            if (!bank_used[b] && !free_of_bank[b].empty()) {
+                                pick = free_of_bank[b][0];
+                                break;
+                            }
+                    }
+                    P.pad_gslot[((size_t) p * L + l) * P.max_list + k] = pick;
+                }
+            }
 }
 
 // ---- mode 1: list-length order + simulated annealing of the two address maps (any code) ----------------------------
@@ -806,21 +850,9 @@ long tuple_joint_placement(TupleSide (&S)[2], const int n_pos, const int M, cons
     }();
     for (long mv = 0; mv < moves && total > floor_e; mv++) {
         const double T = 1.5 * std::pow(0.05 / 1.5, (double) mv / (double) moves);
-        int s = (int) (next() & 1);
+        const int s = (int) (next() & 1);
         if (S[s].n_items < 1) continue;
-        int a = (int) (next() % (uint64_t) S[s].n_items);
-        if (next() & 3) {
-            // three moves in four start from a read that currently collides (min-conflicts): take a random read and, if its
-            // class is taken twice in its service group, move either the tuple read or the reader
-            const size_t nk = S[s].refs[a].size();
-            if (nk == 0) continue;
-            const int k = (int) (next() % nk), tgt = S[s].refs[a][k];
-            if (cell(s, S[s].pos[a] / M, k, S[1 - s].pos[tgt] % M) < 2) continue;
-            if (next() & 1) {
-                a = tgt;
-                s = 1 - s;
-            }
-        }
+        const int a = (int) (next() % (uint64_t) S[s].n_items);
         const int q = (int) (next() % (uint64_t) n_pos), pa = S[s].pos[a];
         if (q == pa) continue;
         const int b = at[s][q];
@@ -1026,6 +1058,22 @@ bool admm_placement_qc(const Code &c, AdmmBlockPlacement &P) {
 
 bool admm_block_placement(const Code &c, int L, bool f32, int mode, AdmmBlockPlacement &out) {
     const AdmmLayout &A = c.admm;
+    // the placement depends on the matrix only (not on alpha / mu / iteration counts): one search per matrix and process
+    // (the (alpha, mu) grid search creates 3721 decoders for one H, qpadmm_params.cpp:64-77)
+    static std::mutex cache_mu;
+    static std::map<std::array<uint64_t, 2>, AdmmBlockPlacement> cache;
+    uint64_t h = 1469598103934665603ull;
+    for (int v : c.edge_var) h = (h ^ (uint64_t) (uint32_t) v) * 1099511628211ull;
+    for (int v : c.row_ptr) h = (h ^ (uint64_t) (uint32_t) v) * 1099511628211ull;
+    const std::array<uint64_t, 2> key = {h, ((uint64_t) c.m << 40) ^ ((uint64_t) c.n << 16) ^ ((uint64_t) L << 4) ^ ((uint64_t) mode << 1) ^ (f32 ? 1u : 0u)};
+    {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) {
+            out = it->second;
+            return true;
+        }
+    }
     out = AdmmBlockPlacement();
     out.L = L;
     out.n_gpass = (A.n_grp + 1 + L - 1) / L;  // +1: at least one padding slot that stays all-zero
@@ -1040,7 +1088,13 @@ bool admm_block_placement(const Code &c, int L, bool f32, int mode, AdmmBlockPla
         out = fresh;
         admm_placement_annealed(c, out, f32, mode >= 1);
     }
+    admm_assign_pads(c, out, done);
     admm_model_cycles(c, out, f32);
+    {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        if (cache.size() >= 64) cache.clear();  // bounded: a local search over matrices must not grow it without limit
+        cache[key] = out;
+    }
     return true;
 }
 

@@ -63,6 +63,19 @@ struct StreamTables {
     const int32_t *col_edge;  // [E] edge ids per variable (checks ascending)
     int32_t m, n, E, nwords;
     int64_t ws_words_per_wave;  // workspace words (of 4 bytes) per wavefront
+    // LDS-DMA ring engine (bp_streamed_ring_kernel, fp32): the sweeps cut into tasks of at most RING_SLOT_LINES message
+    // lines; task i of a sweep belongs to wavefront i mod RING_WAVES.  int4 per task:
+    //   check task {first check, checks, first line, lines | wait << 8 | wait_nostore << 16}
+    //   variable task {first variable, variables, first col_ptr entry, edge lines | wait << 8 | wait_nostore << 16}
+    // wait = vector-memory operations GUARANTEED to be issued behind the task's loads when its data is needed (see the kernel)
+    const int32_t *ctask;
+    const int32_t *vtask;
+    const int32_t *vtask_of_word;  // [nwords] first variable task holding a variable >= 32 * word
+    int32_t n_ctask, n_vtask;
 };
+constexpr int RING_WAVES = 4;        // wavefronts per workgroup of the ring engine
+constexpr int RING_SLOTS = 4;        // ring slots per wavefront (tasks in flight: RING_SLOTS - 1 ahead of the one computed)
+constexpr int RING_SLOT_LINES = 16;  // 256-byte lines per slot (4 KiB)
+constexpr int RING_VAR_EDGE_LINES = 12;  // variable task: at most 12 edge lines + 4 LLR lines
 
 }  // namespace acg

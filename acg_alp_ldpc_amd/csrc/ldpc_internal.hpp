@@ -123,6 +123,11 @@ struct AdmmBlockPlacement {
     std::vector<int> var_of_slot;  // [n_vpass*L] variable id or -1
     std::vector<int> slot_of_grp;  // [n_grp]
     std::vector<int> cell_of_var;  // [n_var]
+    // Entry k of a lane whose own list is shorter than the longest list of its (pass, wavefront) still issues the read:
+    // pad_gslot[(p*L + l) * max_list + k] is the all-zero U slot it reads (-1: the lane has a real entry there).  Mode 1:
+    // always zero_gslot; mode 2: an unoccupied slot in a bank none of the real reads of that service group uses.
+    int max_list = 0;
+    std::vector<int> pad_gslot;
     int n3 = 0;           // mode 1: groups in slots [0, n3) are three-variable checks, the rest one-/two-variable ones
     bool qc = false;
     int Z = 0, tuple = 1;

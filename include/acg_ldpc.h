@@ -77,7 +77,10 @@ typedef struct acg_ldpc_params {
     int32_t lanes_per_frame; /* 0 = auto; 16/32/64: that many lanes of a wavefront cooperate on one frame; 256 (BP also
                                 1024): one workgroup per frame (QP-ADMM then picks 128, 192 or 256 threads itself) */
     int32_t engine;     /* ACG_LDPC_ENGINE_* (BP only) */
-    int32_t reserved;   /* must be 0 */
+    int32_t fast_setup; /* 0 = default: spend up to ~1 s per decoder on the static LDS placement of the QP-ADMM kernel
+                           (bank-conflict search; cached per parity-check matrix inside the process);
+                           1 = skip that search (throw-away decoders, e.g. one per proposal of the check-matrix local
+                           search, optimize_H.cpp:89-104).  Results are identical either way. */
 } acg_ldpc_params;
 
 void acg_ldpc_params_default(acg_ldpc_params *p);

@@ -130,3 +130,33 @@ def test_lds_placement_optimiser(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     before, after, nsets, _ = out.stdout.split()
     assert int(nsets) <= int(after) <= 0.75 * int(before), out.stdout
+
+
+def test_admm_block_placement_quasi_cyclic(tmp_path):
+    """csrc/code.cpp admm_block_placement: for the two quasi-cyclic matrices of the reference (8 x 14 blocks of 20 x 20
+    cyclic shifts, optimize_H.cpp:27-63) the constructive tuple placement (mode 2) must be a valid placement, detect
+    Z = 20 / tuples of 4, and model no more LDS cycles than the annealed one (mode 1) in every access class; data/H.txt
+    is not quasi-cyclic and must fall back to the annealed path unchanged."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "placement_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "placement_check.cpp"),
+                           os.path.join(root, "acg_alp_ldpc_amd", "csrc", "code.cpp"), "-o", exe])
+    for name in ("H05", "optimalH"):
+        out = subprocess.run([exe, "admm", os.path.join(root, "data", name + ".txt"), "256"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        v = [int(x) for x in out.stdout.split()]
+        qc, Z, tup = v[0:3]
+        ann, new, ideal = v[3:6], v[6:9], v[9:12]
+        wave_ann, wave_new = v[12:16], v[16:20]
+        assert (qc, Z, tup) == (1, 20, 4), out.stdout
+        assert all(n <= a_ for n, a_ in zip(new, ann)), out.stdout           # never worse than annealing, class by class
+        assert new[2] == ideal[2]                                             # V stores: conflict-free by construction
+        assert 4 * new[0] + new[1] + new[2] <= 0.8 * (4 * ann[0] + ann[1] + ann[2]), out.stdout   # U rows are read 4x
+        assert all(n >= i for n, i in zip(new, ideal))
+        assert max(wave_new) < max(wave_ann) and sum(wave_new) == sum(wave_ann)   # v-update trips balanced over the wavefronts
+    out = subprocess.run([exe, "admm", os.path.join(root, "data", "H.txt"), "256"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    v = [int(x) for x in out.stdout.split()]
+    assert v[0] == 0 and v[3:6] == v[6:9]

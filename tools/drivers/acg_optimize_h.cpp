@@ -90,6 +90,7 @@ struct Scorer {
                 p.mu = mu;
                 p.max_iter = iters;
                 p.eps_stop = 1e-5;
+                p.fast_setup = 1;  // one decoder per proposal: skip the static LDS placement search
                 acg_ldpc_decoder *d = nullptr;
                 if (acg_ldpc_decoder_create(code, &p, &d)) drv::die("create");
                 f = drv::run_mc(d, cws, n, snr, ntests, noise, 1).fer();
