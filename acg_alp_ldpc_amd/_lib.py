@@ -61,6 +61,7 @@ SYMBOLS = {
     "acg_ldpc_decoder_destroy": (None, [_vp]),
     "acg_ldpc_decoder_name": (C.c_char_p, [_vp]),
     "acg_ldpc_decode_batch": (C.c_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp]),
+    "acg_ldpc_decode_batch_f32": (C.c_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp]),
     "acg_ldpc_decode_batch_dev": (C.c_int, [_vp, _vp, _i32, _i64, _f64, _vp, _vp, _vp, _vp]),
     "acg_ldpc_decoder_sync": (C.c_int, [_vp]),
     "acg_ldpc_decoder_last_kernel_ms": (C.c_float, [_vp]),

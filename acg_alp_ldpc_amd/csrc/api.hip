@@ -9,9 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/acg_ldpc.h"
@@ -34,7 +37,7 @@ const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, 
 const void *bp_kernel_ptr_dbg(int f64, int L);
 const void *bp_block_kernel_ptr_dbg(int f64);
 const void *bp_streamed_ptr(int algo, int f64);
-const void *bp_streamed_ring_ptr(int algo);
+const void *bp_streamed_ring_ptr(int algo, bool nt);
 hipError_t bp_streamed_ring_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid, hipStream_t s);
 hipError_t bp_streamed_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid,
                               int block, hipStream_t s);
@@ -66,6 +69,105 @@ static int upload(const std::vector<T> &h, T **d, size_t min_elems = 1) {
     if (!h.empty()) HIP_OK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return 0;
 }
+
+// A few persistent host threads for the byte shuffling of the host-buffer entry points (pageable user memory -> pinned
+// staging, packed words -> one byte per bit): at 25 M frames/s that is ~30-60 GB/s of memcpy, more than one core moves.
+class HostPool {
+public:
+    explicit HostPool(int n) {
+        for (int i = 0; i < n; i++) th_.emplace_back([this, i] { run(i); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int size() const { return (int) th_.size(); }
+    // fn(part, parts) on every worker thread; returns when all are done
+    void run_all(const std::function<void(int, int)> &fn) {
+        std::unique_lock<std::mutex> lk(mu_);
+        fn_ = &fn;
+        pending_ = (int) th_.size();
+        gen_++;
+        cv_.notify_all();
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void run(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int, int)> *fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                fn = fn_;
+            }
+            (*fn)(id, (int) th_.size());
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)> *fn_ = nullptr;
+    uint64_t gen_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+};
+
+// Double-buffered staging of acg_ldpc_decode_batch / _f32: while the GPU works on chunk c (H2D, kernel, D2H on stream c % 2)
+// the host threads fill the pinned buffer of chunk c + 1 and unpack chunk c - 1.
+struct HostPipe {
+    static constexpr int NBUF = 2;
+    int64_t chunk = 0;       // frames per chunk the buffers are sized for
+    size_t y_bytes = 0;      // bytes per frame of the symbol buffers
+    void *pin_y[NBUF] = {};
+    uint32_t *pin_bits[NBUF] = {};
+    uint8_t *pin_ok[NBUF] = {};
+    int32_t *pin_it[NBUF] = {};
+    void *dev_y[NBUF] = {};
+    uint32_t *dev_bits[NBUF] = {};
+    uint8_t *dev_ok[NBUF] = {};
+    int32_t *dev_it[NBUF] = {};
+    hipStream_t stream[NBUF] = {};
+    hipEvent_t done[NBUF] = {};
+    HostPool *pool = nullptr;
+    void release() {
+        for (int b = 0; b < NBUF; b++) {
+            if (pin_y[b]) (void) hipHostFree(pin_y[b]);
+            if (pin_bits[b]) (void) hipHostFree(pin_bits[b]);
+            if (pin_ok[b]) (void) hipHostFree(pin_ok[b]);
+            if (pin_it[b]) (void) hipHostFree(pin_it[b]);
+            if (dev_y[b]) (void) hipFree(dev_y[b]);
+            if (dev_bits[b]) (void) hipFree(dev_bits[b]);
+            if (dev_ok[b]) (void) hipFree(dev_ok[b]);
+            if (dev_it[b]) (void) hipFree(dev_it[b]);
+            pin_y[b] = dev_y[b] = nullptr;
+            pin_bits[b] = dev_bits[b] = nullptr;
+            pin_ok[b] = dev_ok[b] = nullptr;
+            pin_it[b] = dev_it[b] = nullptr;
+        }
+        chunk = 0;
+    }
+    ~HostPipe() {
+        release();
+        for (int b = 0; b < NBUF; b++) {
+            if (done[b]) (void) hipEventDestroy(done[b]);
+            if (stream[b]) (void) hipStreamDestroy(stream[b]);
+        }
+        delete pool;
+    }
+};
 
 }  // namespace acg
 
@@ -101,6 +203,7 @@ struct acg_ldpc_decoder {
     StreamTables stab{};
     const void *skernel = nullptr;
     const void *sring = nullptr;  // LDS-DMA ring variant (fp32), null = not available for this code
+    int sring_per_cu = 2;
     uint32_t *sws = nullptr;
     int sgrid = 0;
     // ADMM
@@ -111,6 +214,7 @@ struct acg_ldpc_decoder {
     uint8_t *st_ok = nullptr;
     int32_t *st_iters = nullptr;
     int64_t st_frames = 0;
+    HostPipe *pipe = nullptr;  // pipelined staging of the host-buffer entry points (created on first use)
     // MC through engines without an in-kernel generator (streamed): chunk buffers
     float *mc_y = nullptr;
     int64_t mc_frames = 0;
@@ -254,7 +358,7 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
     const size_t ts = d->f64 ? 8 : 4;
     // LDS-DMA ring engine (fp32, node degrees that fit a ring slot): cut the sweeps into tasks
     size_t hb_bytes = (size_t) t.nwords * 64 * 4;  // HB[nwords][64] (u32)
-    if (!d->f64 && c.max_cdeg <= RING_SLOT_LINES && c.max_vdeg <= RING_VAR_EDGE_LINES && getenv("ACG_STREAM_NO_RING") == nullptr) {
+    if (!d->f64 && c.max_cdeg <= RING_MAX_CDEG && c.max_vdeg <= RING_MAX_VDEG && getenv("ACG_STREAM_NO_RING") == nullptr) {
         struct Task { int first, cnt, base, lines; };
         std::vector<Task> ct, vt;
         for (int i = 0; i < c.m;) {
@@ -314,8 +418,12 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
         UP32S(ce, col_edge)
         t.n_ctask = (int32_t) ct.size();
         t.n_vtask = (int32_t) vt.size();
-        d->sring = bp_streamed_ring_ptr((d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0);
-        HIP_OK(hipFuncSetAttribute(d->sring, hipFuncAttributeMaxDynamicSharedMemorySize, RING_WAVES * RING_SLOTS * RING_SLOT_LINES * 256));
+        // slabs of all resident workgroups beyond the 256 MiB Infinity Cache: stream them with non-temporal accesses
+        const size_t slab_bytes = ((size_t) (c.E + c.n) * 64 * ts + (size_t) vt.size() * 64);
+        bool nt = slab_bytes * 3 * (size_t) d->cu_count > ((size_t) 256 << 20);
+        if (getenv("ACG_STREAM_NT")) nt = atoi(getenv("ACG_STREAM_NT")) != 0;  // developer A/B only
+        d->sring = bp_streamed_ring_ptr((d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0, nt);
+        HIP_OK(hipFuncSetAttribute(d->sring, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
         hb_bytes = std::max(hb_bytes, (size_t) vt.size() * 64);  // ring engine: one byte per (variable task, frame)
     }
 #undef UP32S
@@ -328,6 +436,12 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
     // 2 workgroups per CU (x 4 wavefronts = 8 waves/CU keep > 1 MB of 256-byte lines in flight per CU);
     // each resident workgroup owns one slab: M[E][64] + LLR[n][64] + HB[nwords][64]
     d->sgrid = 2 * d->cu_count;
+    if (d->sring) {  // ring engine: as many workgroups per CU as their rings fit in LDS
+        int per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, d->sring, RING_WAVES * 64, RING_LDS_BYTES) != hipSuccess) per_cu = 2;
+        d->sring_per_cu = std::max(1, std::min(per_cu, ACG_RING_MAX_PER_CU));
+        d->sgrid = std::max(d->sgrid, d->sring_per_cu * d->cu_count);
+    }
     const size_t ws_bytes = (size_t) d->sgrid * (size_t) t.ws_words_per_wave * 4;
     if (t.ws_words_per_wave < (int64_t) (c.E + c.n) * 64) {  // the kernels index the slab without further checks
         set_error("internal: streamed-engine slab size not set");
@@ -607,6 +721,7 @@ void acg_ldpc_decoder_destroy(acg_ldpc_decoder *d) {
     if (d->st_bits) (void) hipFree(d->st_bits);
     if (d->st_ok) (void) hipFree(d->st_ok);
     if (d->st_iters) (void) hipFree(d->st_iters);
+    delete d->pipe;
     if (d->cw_dev) (void) hipFree(d->cw_dev);
     if (d->counters) (void) hipFree(d->counters);
     if (d->work_ring) (void) hipFree(d->work_ring);
@@ -671,7 +786,7 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         const int per_cu = (W <= 4) ? 2 : 1;
         int grid = (int) std::min<int64_t>(tiles, (int64_t) per_cu * d->cu_count);
         if (d->sring && !a.dbg_c2v && !a.dbg_v2c) {
-            grid = (int) std::min<int64_t>(tiles, 2 * (int64_t) d->cu_count);  // 64 KiB of ring per workgroup: two per CU
+            grid = (int) std::min<int64_t>(tiles, (int64_t) d->sring_per_cu * d->cu_count);
             HIP_OK(bp_streamed_ring_launch(d->sring, d->stab, a, d->sws, grid, s));
         } else {
             HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
@@ -735,6 +850,136 @@ static int ensure_staging(acg_ldpc_decoder *d, int64_t frames) {
     return 0;
 }
 
+static int ensure_pipe(acg_ldpc_decoder *d, int64_t chunk, size_t y_bytes) {
+    if (!d->pipe) {
+        d->pipe = new HostPipe();
+        for (int b = 0; b < HostPipe::NBUF; b++) {
+            HIP_OK(hipStreamCreateWithFlags(&d->pipe->stream[b], hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&d->pipe->done[b], hipEventDisableTiming));
+        }
+        const unsigned hc = std::thread::hardware_concurrency();
+        d->pipe->pool = new HostPool((int) std::max(2u, std::min(8u, hc ? hc / 2 : 2u)));
+    }
+    HostPipe &P = *d->pipe;
+    if (chunk <= P.chunk && y_bytes <= P.y_bytes) return 0;
+    P.release();
+    const int nwords = (d->c.n + 31) / 32;
+    for (int b = 0; b < HostPipe::NBUF; b++) {
+        HIP_OK(hipHostMalloc(&P.pin_y[b], (size_t) chunk * y_bytes, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void **) &P.pin_bits[b], (size_t) chunk * nwords * 4, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void **) &P.pin_ok[b], (size_t) chunk, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void **) &P.pin_it[b], (size_t) chunk * 4, hipHostMallocDefault));
+        HIP_OK(hipMalloc(&P.dev_y[b], (size_t) chunk * y_bytes));
+        HIP_OK(hipMalloc((void **) &P.dev_bits[b], (size_t) chunk * nwords * 4));
+        HIP_OK(hipMalloc((void **) &P.dev_ok[b], (size_t) chunk));
+        HIP_OK(hipMalloc((void **) &P.dev_it[b], (size_t) chunk * 4));
+    }
+    P.chunk = chunk;
+    P.y_bytes = y_bytes;
+    return 0;
+}
+
+// packed words -> one byte per bit, 8 bits at a time through a 256-entry table
+static void unpack_bits(const uint32_t *words, int nwords, int n, int64_t frames, uint8_t *bits) {
+    static const std::vector<uint64_t> lut = [] {
+        std::vector<uint64_t> t(256);
+        for (int x = 0; x < 256; x++) {
+            uint64_t v = 0;
+            for (int k = 0; k < 8; k++) v |= (uint64_t) ((x >> k) & 1) << (8 * k);
+            t[x] = v;
+        }
+        return t;
+    }();
+    for (int64_t f = 0; f < frames; f++) {
+        uint8_t *b = bits + (size_t) f * n;
+        const uint8_t *w = reinterpret_cast<const uint8_t *>(words + (size_t) f * nwords);
+        int v = 0;
+        for (; v + 8 <= n; v += 8) std::memcpy(b + v, &lut[w[v >> 3]], 8);
+        for (; v < n; v++) b[v] = (w[v >> 3] >> (v & 7)) & 1u;
+    }
+}
+
+// Host buffers in, host buffers out: chunks of the batch travel through two pinned staging sets.  Per chunk c (set c % 2):
+// host threads copy the symbols into pinned memory -> H2D, decode, D2H of words / flags / sweep counts on the set's
+// stream -> host threads expand the words into one byte per bit.  Chunk c + 1 is packed and chunk c - 1 unpacked while
+// the GPU works on chunk c.  elem = 8 (double symbols: exact LLRs, channel.h:14-16) or 4 (float symbols).
+static int decode_batch_host(acg_ldpc_decoder *d, const void *y, int elem, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
+                             int32_t *iters) {
+    const int n = d->c.n, nwords = (n + 31) / 32;
+    const size_t y_bytes = (size_t) n * elem;
+    // small batches (single frames: the reference's decode()) take one chunk; large ones ~64k frames per chunk
+    const int64_t chunk = std::min<int64_t>(frames, 1 << 16);
+    if (int rc = ensure_pipe(d, chunk, y_bytes)) return rc;
+    HostPipe &P = *d->pipe;
+    const int64_t nchunks = (frames + chunk - 1) / chunk;
+    const bool threads = frames >= 4096;  // tiny batches: the hand-off to the pool costs more than the copy
+    auto chunk_frames = [&](int64_t c) { return std::min(chunk, frames - c * chunk); };
+    auto pack = [&](int64_t c) {
+        const int b = (int) (c % HostPipe::NBUF);
+        const int64_t fc = chunk_frames(c);
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(y) + (size_t) c * chunk * y_bytes;
+        unsigned char *dst = reinterpret_cast<unsigned char *>(P.pin_y[b]);
+        const size_t total = (size_t) fc * y_bytes;
+        if (!threads) {
+            std::memcpy(dst, src, total);
+            return;
+        }
+        P.pool->run_all([&](int part, int parts) {
+            const size_t lo = total * part / parts / 64 * 64, hi = (part + 1 == parts) ? total : total * (part + 1) / parts / 64 * 64;
+            std::memcpy(dst + lo, src + lo, hi - lo);
+        });
+    };
+    auto submit = [&](int64_t c) -> int {
+        const int b = (int) (c % HostPipe::NBUF);
+        const int64_t fc = chunk_frames(c);
+        hipStream_t s = P.stream[b];
+        HIP_OK(hipMemcpyAsync(P.dev_y[b], P.pin_y[b], (size_t) fc * y_bytes, hipMemcpyHostToDevice, s));
+        DecodeArgs a{};
+        a.y = P.dev_y[b];
+        a.y_is_f64 = (elem == 8) ? 1 : 0;
+        a.frames = fc;
+        fill_channel(a, snr);
+        a.out_bits = P.dev_bits[b];
+        a.out_ok = P.dev_ok[b];
+        a.out_iters = P.dev_it[b];
+        if (int rc = launch_decode(d, a, s)) return rc;
+        HIP_OK(hipMemcpyAsync(P.pin_bits[b], P.dev_bits[b], (size_t) fc * nwords * 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(P.pin_ok[b], P.dev_ok[b], (size_t) fc, hipMemcpyDeviceToHost, s));
+        if (iters) HIP_OK(hipMemcpyAsync(P.pin_it[b], P.dev_it[b], (size_t) fc * 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipEventRecord(P.done[b], s));
+        return 0;
+    };
+    auto collect = [&](int64_t c) -> int {
+        const int b = (int) (c % HostPipe::NBUF);
+        const int64_t fc = chunk_frames(c), f0 = c * chunk;
+        HIP_OK(hipEventSynchronize(P.done[b]));
+        std::memcpy(ok + f0, P.pin_ok[b], (size_t) fc);
+        if (iters) std::memcpy(iters + f0, P.pin_it[b], (size_t) fc * 4);
+        if (!threads) {
+            unpack_bits(P.pin_bits[b], nwords, n, fc, bits + (size_t) f0 * n);
+            return 0;
+        }
+        P.pool->run_all([&](int part, int parts) {
+            const int64_t lo = fc * part / parts, hi = fc * (part + 1) / parts;
+            unpack_bits(P.pin_bits[b] + (size_t) lo * nwords, nwords, n, hi - lo, bits + (size_t) (f0 + lo) * n);
+        });
+        return 0;
+    };
+    pack(0);
+    for (int64_t c = 0; c < nchunks; c++) {
+        if (int rc = submit(c)) return rc;
+        if (c + 1 < nchunks) {
+            // set (c + 1) % 2 was last used by chunk c - 1: its results must be out before its buffers are refilled
+            if (c >= 1)
+                if (int rc = collect(c - 1)) return rc;
+            pack(c + 1);
+        } else if (c >= 1) {
+            if (int rc = collect(c - 1)) return rc;
+        }
+    }
+    return collect(nchunks - 1);
+}
+
 int acg_ldpc_decode_batch(acg_ldpc_decoder *d, const double *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
                           int32_t *iters) {
     if (!d) {
@@ -748,47 +993,23 @@ int acg_ldpc_decode_batch(acg_ldpc_decoder *d, const double *y, int64_t frames, 
     if (frames == 0) return 0;
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_OK(hipSetDevice(d->device));
-    const int n = d->c.n, nwords = (n + 31) / 32;
-    // bounded chunks keep the staging buffers small for huge host batches
-    const int64_t chunk_max = 1 << 18;
-    std::vector<uint32_t> hbits;
-    for (int64_t f0 = 0; f0 < frames; f0 += chunk_max) {
-        const int64_t fc = std::min(chunk_max, frames - f0);
-        if (int rc = ensure_staging(d, fc)) return rc;
-        HIP_OK(hipMemcpyAsync(d->st_y, y + (size_t) f0 * n, (size_t) fc * n * sizeof(double), hipMemcpyHostToDevice, d->stream));
-        DecodeArgs a{};
-        a.y = d->st_y;
-        a.y_is_f64 = 1;
-        a.frames = fc;
-        fill_channel(a, snr);
-        a.out_bits = d->st_bits;
-        a.out_ok = d->st_ok;
-        a.out_iters = d->st_iters;
-        if (int rc = launch_decode(d, a, d->stream)) return rc;
-        hbits.resize((size_t) fc * nwords);
-        HIP_OK(hipMemcpyAsync(hbits.data(), d->st_bits, hbits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
-        HIP_OK(hipMemcpyAsync(ok + f0, d->st_ok, (size_t) fc, hipMemcpyDeviceToHost, d->stream));
-        if (iters) HIP_OK(hipMemcpyAsync(iters + f0, d->st_iters, (size_t) fc * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-        HIP_OK(hipStreamSynchronize(d->stream));
-        // packed words -> one byte per bit, 8 bits at a time through a 256-entry table
-        static const std::vector<uint64_t> lut = [] {
-            std::vector<uint64_t> t(256);
-            for (int x = 0; x < 256; x++) {
-                uint64_t v = 0;
-                for (int k = 0; k < 8; k++) v |= (uint64_t) ((x >> k) & 1) << (8 * k);
-                t[x] = v;
-            }
-            return t;
-        }();
-        for (int64_t f = 0; f < fc; f++) {
-            uint8_t *b = bits + (size_t) (f0 + f) * n;
-            const uint8_t *w = reinterpret_cast<const uint8_t *>(&hbits[(size_t) f * nwords]);
-            int v = 0;
-            for (; v + 8 <= n; v += 8) std::memcpy(b + v, &lut[w[v >> 3]], 8);
-            for (; v < n; v++) b[v] = (w[v >> 3] >> (v & 7)) & 1u;
-        }
+    return decode_batch_host(d, y, 8, frames, snr, bits, ok, iters);
+}
+
+int acg_ldpc_decode_batch_f32(acg_ldpc_decoder *d, const float *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
+                              int32_t *iters) {
+    if (!d) {
+        set_error("null decoder");
+        return 1;
     }
-    return 0;
+    if (frames < 0 || (frames > 0 && (!y || !bits || !ok))) {
+        set_error("null buffer");
+        return 1;
+    }
+    if (frames == 0) return 0;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_OK(hipSetDevice(d->device));
+    return decode_batch_host(d, y, 4, frames, snr, bits, ok, iters);
 }
 
 int acg_ldpc_decoder_sync(acg_ldpc_decoder *d) {

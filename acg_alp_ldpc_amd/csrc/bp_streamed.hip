@@ -408,12 +408,24 @@ __global__ void __launch_bounds__(512) bp_streamed_kernel(const StreamTables t, 
 // under-counting waits a little longer, over-counting would read a slot before it has landed.
 // The DMA is inline assembly (M0 = LDS destination) so the compiler neither tracks it nor drains it early; a wavefront
 // reads only slots it filled itself, for which its own counted vmcnt is the ordering the hardware asks for.
+template <bool NT>
 __device__ __forceinline__ void ring_dma16(const void *gsrc, uint32_t lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    if (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
+}
+template <bool NT>
+__device__ __forceinline__ void ring_store(float *p, float v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
 }
 
 // wait until at most n (rounded down to a multiple of 4) vector-memory operations of this wavefront are outstanding
@@ -427,7 +439,7 @@ __device__ __forceinline__ void ring_wait_vmcnt(int n) {
     }
 }
 
-template <int ALGO>
+template <int ALGO, bool NT>
 struct RingPass {
     using T = float;
     using B = FpBits<float>;
@@ -473,7 +485,7 @@ struct RingPass {
             for (int j = 0; j < D; ++j) o[j] = ms_scale * ((j == am) ? m2 : m1);
         }
 #pragma unroll
-        for (int j = 0; j < D; ++j) out[j * 64] = B::from((B::to(o[j]) & ~B::SIGN) | ((S ^ B::to(x[j])) & B::SIGN));
+        for (int j = 0; j < D; ++j) ring_store<NT>(out + j * 64, B::from((B::to(o[j]) & ~B::SIGN) | ((S ^ B::to(x[j])) & B::SIGN)));
         return S;
     }
 
@@ -503,7 +515,7 @@ struct RingPass {
             ob[k] = (B::to(mg) & ~B::SIGN & ~(U) 1) | hard | ((xk <= (T) 0) ? B::SIGN : (U) 0);
         }
 #pragma unroll
-        for (int k = 0; k < D; ++k) M[(size_t) eid[k] * 64 + lane] = B::from(ob[k]);
+        for (int k = 0; k < D; ++k) ring_store<NT>(M + (size_t) eid[k] * 64 + lane, B::from(ob[k]));
         return (uint32_t) hard;
     }
 };
@@ -525,12 +537,13 @@ struct RingPass {
         default: break;                                                                                         \
     }
 
-template <int ALGO>
-__global__ void __launch_bounds__(RING_WAVES * 64, 2) bp_streamed_ring_kernel(const StreamTables t, const DecodeArgs a, uint32_t *ws) {
+// NT: non-temporal loads and stores for slabs that cannot stay in the 256 MiB Infinity Cache between two sweeps anyway
+template <int ALGO, bool NT>
+__global__ void __launch_bounds__(RING_WAVES * 64, (RING_LDS_BYTES <= 32 * 1024 ? 5 : (RING_LDS_BYTES <= 40 * 1024 ? 4 : (RING_LDS_BYTES <= 52 * 1024 ? 3 : 2)))) bp_streamed_ring_kernel(const StreamTables t, const DecodeArgs a, uint32_t *ws) {
     using T = float;
     using B = FpBits<float>;
     using U = uint32_t;
-    using P = RingPass<ALGO>;
+    using P = RingPass<ALGO, NT>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring_lds[];
     __shared__ uint32_t bad_lds[RING_WAVES][64];
     __shared__ unsigned long long tile_lds;
@@ -558,7 +571,7 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 2) bp_streamed_ring_kernel(co
 #pragma unroll
         for (int j = 0; j < RING_SLOT_LINES / 4; ++j)
             if (4 * j < nl)
-                if (lane < 16 * (nl - 4 * j)) ring_dma16(src + j * 1024, dst + j * 1024);
+                if (lane < 16 * (nl - 4 * j)) ring_dma16<NT>(src + j * 1024, dst + j * 1024);
     };
     auto issue_var = [&](int i) {  // edge lines gathered four per instruction + the LLR lines of the task's variables
         const int ti = w + i * W;
@@ -571,9 +584,9 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 2) bp_streamed_ring_kernel(co
                 const int e0 = sload(t.col_edge, cp0 + 4 * j), e1 = sload(t.col_edge, cp0 + 4 * j + 1);
                 const int e2 = sload(t.col_edge, cp0 + 4 * j + 2), e3 = sload(t.col_edge, cp0 + 4 * j + 3);
                 const int e = (q16 == 0) ? e0 : ((q16 == 1) ? e1 : ((q16 == 2) ? e2 : e3));
-                if (4 * j + q16 < nel) ring_dma16(Mb + (size_t) e * 256 + (size_t) l16 * 16, dst + j * 1024);
+                if (4 * j + q16 < nel) ring_dma16<NT>(Mb + (size_t) e * 256 + (size_t) l16 * 16, dst + j * 1024);
             }
-        if (q16 < nv) ring_dma16(LLRb + (size_t) v0 * 256 + (size_t) lane * 16, dst + RING_VAR_EDGE_LINES * 256);
+        if (q16 < nv) ring_dma16<NT>(LLRb + (size_t) v0 * 256 + (size_t) lane * 16, dst + RING_VAR_EDGE_LINES * 256);
     };
 
     for (;;) {
@@ -653,9 +666,9 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 2) bp_streamed_ring_kernel(co
                     const int d = b1 - b0;
                     const T llr = slot[(RING_VAR_EDGE_LINES + vi) * 64];
                     uint32_t hard = (llr <= (T) 0) ? 1u : 0u;  // isolated variable: estimate() == channel LLR
-                    int eid[RING_VAR_EDGE_LINES];
+                    int eid[RING_MAX_VDEG];
 #pragma unroll
-                    for (int k = 0; k < RING_VAR_EDGE_LINES; ++k)
+                    for (int k = 0; k < RING_MAX_VDEG; ++k)
                         if (k < d) eid[k] = sload(t.col_edge, b0 + k);
 #define ACG_CALL(D) hard = P::template var<D>(slot + (b0 - cp0) * 64, M, eid, lane, llr)
                     ACG_DEG12_SWITCH(d, ACG_CALL)
@@ -698,15 +711,16 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 2) bp_streamed_ring_kernel(co
     }
 }
 
-const void *bp_streamed_ring_ptr(int algo) {
-    return algo == 0 ? (const void *) bp_streamed_ring_kernel<0> : (const void *) bp_streamed_ring_kernel<1>;
+const void *bp_streamed_ring_ptr(int algo, bool nt) {
+    if (nt) return algo == 0 ? (const void *) bp_streamed_ring_kernel<0, true> : (const void *) bp_streamed_ring_kernel<1, true>;
+    return algo == 0 ? (const void *) bp_streamed_ring_kernel<0, false> : (const void *) bp_streamed_ring_kernel<1, false>;
 }
 
 hipError_t bp_streamed_ring_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid, hipStream_t s) {
     StreamTables tt = t;
     DecodeArgs aa = a;
     void *args[3] = {&tt, &aa, &ws};
-    return hipLaunchKernel(kernel, dim3(grid), dim3(RING_WAVES * 64), args, (size_t) RING_WAVES * RING_SLOTS * RING_SLOT_LINES * 256, s);
+    return hipLaunchKernel(kernel, dim3(grid), dim3(RING_WAVES * 64), args, (size_t) RING_LDS_BYTES, s);
 }
 
 const void *bp_streamed_ptr(int algo, int f64) {

@@ -73,9 +73,23 @@ struct StreamTables {
     const int32_t *vtask_of_word;  // [nwords] first variable task holding a variable >= 32 * word
     int32_t n_ctask, n_vtask;
 };
+#ifndef ACG_RING_SLOTS
+#define ACG_RING_SLOTS 3
+#endif
+#ifndef ACG_RING_SLOT_LINES
+#define ACG_RING_SLOT_LINES 16
+#endif
+#ifndef ACG_RING_MAX_PER_CU
+#define ACG_RING_MAX_PER_CU 4
+#endif
 constexpr int RING_WAVES = 4;        // wavefronts per workgroup of the ring engine
-constexpr int RING_SLOTS = 4;        // ring slots per wavefront (tasks in flight: RING_SLOTS - 1 ahead of the one computed)
-constexpr int RING_SLOT_LINES = 16;  // 256-byte lines per slot (4 KiB)
-constexpr int RING_VAR_EDGE_LINES = 12;  // variable task: at most 12 edge lines + 4 LLR lines
+constexpr int RING_SLOTS = ACG_RING_SLOTS;            // ring slots per wavefront (tasks in flight: RING_SLOTS - 1 ahead of the one computed)
+constexpr int RING_SLOT_LINES = ACG_RING_SLOT_LINES;  // 256-byte lines per slot
+constexpr int RING_VAR_EDGE_LINES = RING_SLOT_LINES - 4;  // variable task: edge lines + up to 4 LLR lines
+constexpr int RING_MAX_CDEG = RING_SLOT_LINES < 16 ? RING_SLOT_LINES : 16;          // a node must fit in one slot
+constexpr int RING_MAX_VDEG = RING_VAR_EDGE_LINES < 12 ? RING_VAR_EDGE_LINES : 12;  // (and in the kernels' degree switches)
+constexpr int RING_LDS_BYTES = RING_WAVES * RING_SLOTS * RING_SLOT_LINES * 256;
+// the counted waits must stay within the 6-bit vmcnt field: (slots - 1) tasks of loads + stores behind a task's loads
+static_assert((RING_SLOTS - 1) * (RING_SLOT_LINES + RING_SLOT_LINES / 4 + 1) <= 63, "ring too deep for vmcnt");
 
 }  // namespace acg

@@ -88,16 +88,19 @@ class Decoder:
         return bits[0], bool(ok[0])
 
     def decode_batch(self, H, Y, snr):
+        """Y: frames x n channel symbols.  float64 (default): the reference's exact LLRs; a float32 array travels as
+        float32 (half the PCIe bytes, acg_ldpc_decode_batch_f32)."""
         h, code = self.handle(H)
-        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        f32 = isinstance(Y, np.ndarray) and Y.dtype == np.float32
+        Y = np.ascontiguousarray(Y, dtype=np.float32 if f32 else np.float64)
         if Y.ndim != 2 or Y.shape[1] != code.n:
             raise ValueError("Y must be frames x n")
         F = Y.shape[0]
-        bits = np.zeros((F, code.n), dtype=np.uint8)
-        ok = np.zeros(F, dtype=np.uint8)
-        iters = np.zeros(F, dtype=np.int32)
-        check(lib().acg_ldpc_decode_batch(h, Y.ctypes.data, F, float(snr), bits.ctypes.data, ok.ctypes.data,
-                                          iters.ctypes.data))
+        bits = np.empty((F, code.n), dtype=np.uint8)
+        ok = np.empty(F, dtype=np.uint8)
+        iters = np.empty(F, dtype=np.int32)
+        fn = lib().acg_ldpc_decode_batch_f32 if f32 else lib().acg_ldpc_decode_batch
+        check(fn(h, Y.ctypes.data, F, float(snr), bits.ctypes.data, ok.ctypes.data, iters.ctypes.data))
         return bits, ok, iters
 
     def decode_batch_dev(self, H, y_ptr, y_is_f64, frames, snr, bits_ptr, ok_ptr, iters_ptr=None, stream=None):

@@ -130,9 +130,17 @@ const char *acg_ldpc_decoder_name(const acg_ldpc_decoder *dec);
  *   bits   host, frames*n bytes (0/1).  BP failure -> zeros (the reference returns an empty vector, bp.h:198)
  *   ok     host, frames bytes: the reference's bool (BP: zero syndrome reached; QP-ADMM: always 1 unless the
  *          e_min*mu<=alpha guard fires, qp_admm.h:112-114,177)
- *   iters  host, frames int32 or NULL: sweeps executed until exit (BP: iteration of the first zero syndrome) */
+ *   iters  host, frames int32 or NULL: sweeps executed until exit (BP: iteration of the first zero syndrome)
+ * Large batches are pipelined in chunks of 65536 frames through two pinned staging sets (host threads copy / unpack
+ * while the GPU decodes the previous chunk); the rate is PCIe-bound: 8 bytes in + 1 byte out per symbol. */
 int acg_ldpc_decode_batch(acg_ldpc_decoder *dec, const double *y, int64_t frames, double snr, uint8_t *bits,
                           uint8_t *ok, int32_t *iters);
+
+/* Same with single-precision symbols (half the PCIe bytes).  The LLR is formed as (double) y * (2 / sigma^2), rounded
+ * to the kernel's message type — the path of acg_ldpc_decode_batch_dev with y_is_f64 = 0.  A caller holding doubles
+ * who wants the reference's exact llr = 2y / sigma^2 (channel.h:14-16) uses acg_ldpc_decode_batch. */
+int acg_ldpc_decode_batch_f32(acg_ldpc_decoder *dec, const float *y, int64_t frames, double snr, uint8_t *bits,
+                              uint8_t *ok, int32_t *iters);
 
 /* Same, buffers already resident in HBM (this is what bench.py times).
  *   y_dev        device, frames*n of float (y_is_f64=0) or double (y_is_f64=1)

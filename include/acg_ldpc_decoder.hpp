@@ -68,20 +68,32 @@ public:
         return out;
     }
 
-    // the C handle for Monte-Carlo runs (acg_ldpc_mc_run)
+    // the C handle for Monte-Carlo runs (acg_ldpc_mc_run).  The reference hands H to every decode() and re-analyses it
+    // (bp.h:136-153, qp_admm.h:15-21); here the analysed graph is cached on the CONTENT of H, so a matrix that is modified
+    // or whose storage is recycled can never meet a stale handle.  The content hash reads the packed words of
+    // vector<bool> (libstdc++) — ~1 us for a 160 x 280 matrix — and the dense copy is only built on a miss.
     acg_ldpc_decoder *handle(const TMatrix &H) {
         std::lock_guard<std::mutex> lk(mu_);
         const int m = (int) H.size(), n = (int) H[0].size();
-        std::vector<uint8_t> dense((size_t) m * n);
         uint64_t h = 1469598103934665603ull;
-        for (int i = 0; i < m; i++)
-            for (int j = 0; j < n; j++) {
-                dense[(size_t) i * n + j] = H[i][j];
-                h = (h ^ (uint64_t) H[i][j]) * 1099511628211ull;
-            }
+        for (int i = 0; i < m; i++) {
+#if defined(__GLIBCXX__)
+            // whole 64-bit words of the row, then the tail bits (bits beyond size() in the last word are unspecified)
+            const unsigned long *wp = H[i].begin()._M_p;
+            const int full = n / (int) (8 * sizeof(unsigned long));
+            for (int w = 0; w < full; w++) h = (h ^ (uint64_t) wp[w]) * 1099511628211ull;
+            for (int j = full * (int) (8 * sizeof(unsigned long)); j < n; j++) h = (h ^ (uint64_t) H[i][j]) * 1099511628211ull;
+#else
+            for (int j = 0; j < n; j++) h = (h ^ (uint64_t) H[i][j]) * 1099511628211ull;
+#endif
+            h = (h ^ 0x9E3779B97F4A7C15ull) * 1099511628211ull;  // row separator
+        }
         const Key key{m, n, h};
         auto it = cache_.find(key);
         if (it != cache_.end()) return it->second.dec;
+        std::vector<uint8_t> dense((size_t) m * n);
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j < n; j++) dense[(size_t) i * n + j] = H[i][j];
         Entry e{};
         check(acg_ldpc_code_from_dense(dense.data(), m, n, &e.code));
         acg_ldpc_params p;

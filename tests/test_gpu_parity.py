@@ -745,6 +745,36 @@ def test_one_handle_two_streams_overlapping_launches(A, oracle, matrices, pcm, k
     dec.close()
 
 
+def test_host_api_pipelined_chunks_double_and_float(A, oracle, matrices, pcm):
+    """acg_ldpc_decode_batch / _f32 stream large host batches through two pinned staging sets in chunks of 65536 frames
+    (host threads pack / unpack while the GPU decodes): a batch of three chunks with a ragged tail must come back frame
+    for frame equal to the device-buffer entry point on the same symbols, and equal to the oracle on a sample from every
+    chunk.  float32 symbols: the oracle is fed the same rounded symbols."""
+    import torch
+    Hm, H = matrices["H05"], pcm["H05"]
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 1024, 11)
+    snr, F = -1.5, 2 * 65536 + 9001
+    y64 = A.transmit_frames(cws, snr, first_frame=5, frames=F)
+    pick = np.r_[0:300, 65536 - 150:65536 + 150, 2 * 65536 - 150:2 * 65536 + 150, F - 300:F]
+    nw = (H.n + 31) // 32
+    for dec, ofn in ((A.BeliefPropagationDecoder(50), lambda yy: oracle.bp_decode(Hm, yy, snr, 50, threads=8)),
+                     (A.QPADMMDecoder(1.95, 0.5, 60, 1e-5), lambda yy: oracle.qpadmm_decode(Hm, yy, snr, 1.95, 0.5, 60, 1e-5, threads=8))):
+        for y in (y64, y64.astype(np.float32)):
+            bits, ok, it = dec.decode_batch(H, y, snr)
+            yd = torch.from_numpy(y).cuda()
+            db = torch.zeros((F, nw), dtype=torch.int32, device="cuda")
+            dk = torch.zeros(F, dtype=torch.uint8, device="cuda")
+            di = torch.zeros(F, dtype=torch.int32, device="cuda")
+            dec.decode_batch_dev(H, yd.data_ptr(), y.dtype == np.float64, F, snr, db.data_ptr(), dk.data_ptr(), di.data_ptr())
+            dec.sync(H)
+            ref_bits = np.unpackbits(db.cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :H.n]
+            assert (bits == ref_bits).all() and (ok == dk.cpu().numpy()).all() and (it == di.cpu().numpy()).all(), (dec.name(), y.dtype)
+            ob, ook, oit = ofn(y[pick].astype(np.float64))
+            assert (bits[pick] == ob).all() and (ok[pick] == ook).all() and (it[pick] == oit).all(), (dec.name(), y.dtype)
+        dec.close()
+
+
 # ---------------------------------------------------------------------------------------- workgroup-per-frame fused BP
 @pytest.mark.parametrize("lpf", [256, 1024])
 def test_block_mode_equals_oracle_on_h05(A, oracle, matrices, pcm, lpf):

@@ -75,6 +75,86 @@ __global__ void __launch_bounds__(THREADS) stream_lds(float *slabs, int lines, i
     }
 }
 
+// (C) as (B) but reading slab A and writing slab B (ping-pong, swapped every sweep), optionally with non-temporal accesses
+template <int P, bool NT>
+__global__ void __launch_bounds__(THREADS) stream_lds_pp(float *slabs, float *slabs2, int lines, int sweeps) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
+    float *S = slabs + (size_t) blockIdx.x * lines * 64, *D = slabs2 + (size_t) blockIdx.x * lines * 64;
+    float *ring = lds + (size_t) w * 2 * P * 64;
+    for (int s = 0; s < sweeps; ++s) {
+        int buf = 0;
+        int e0 = w * P;
+        if (e0 < lines)
+#pragma unroll
+            for (int g = 0; g < P; ++g)
+                if (e0 + g < lines) __builtin_amdgcn_global_load_lds(S + (size_t) (e0 + g) * 64 + lane, ring + (buf * P + g) * 64, 4, 0, NT ? 2 : 0);
+        for (; e0 < lines; e0 += W * P) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const int e1 = e0 + W * P;
+            if (e1 < lines)
+#pragma unroll
+                for (int g = 0; g < P; ++g)
+                    if (e1 + g < lines)
+                        __builtin_amdgcn_global_load_lds(S + (size_t) (e1 + g) * 64 + lane, ring + ((buf ^ 1) * P + g) * 64, 4, 0, NT ? 2 : 0);
+#pragma unroll
+            for (int g = 0; g < P; ++g)
+                if (e0 + g < lines) {
+                    const float x = ring[(buf * P + g) * 64 + lane] * 1.0001f + 1.0f;
+                    if (NT) __builtin_nontemporal_store(x, D + (size_t) (e0 + g) * 64 + lane);
+                    else D[(size_t) (e0 + g) * 64 + lane] = x;
+                }
+            buf ^= 1;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        float *t = S;
+        S = D;
+        D = t;
+    }
+}
+
+// (D) wide both ways: 1 KiB per load instruction (global_load_lds_dwordx4: 16 lanes per line), the result written back into
+// the LDS copy and stored with global_store_dwordx4 (each lane reads 16 bytes of the lane-linear image back): a quarter of
+// the vector-memory instructions of (B) on either side
+template <int P>  // P lines per buffer, multiple of 4
+__global__ void __launch_bounds__(THREADS) stream_lds_wide(float *slabs, int lines, int sweeps) {
+    extern __shared__ float lds[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
+    float *S = slabs + (size_t) blockIdx.x * lines * 64;
+    float *ring = lds + (size_t) w * 2 * P * 64;
+    for (int s = 0; s < sweeps; ++s) {
+        int buf = 0;
+        int e0 = w * P;
+        if (e0 < lines)
+#pragma unroll
+            for (int g = 0; g < P; g += 4)
+                if (e0 + g < lines) __builtin_amdgcn_global_load_lds(S + (size_t) (e0 + g) * 64 + lane * 4, ring + (buf * P + g) * 64, 16, 0, 0);
+        for (; e0 < lines; e0 += W * P) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const int e1 = e0 + W * P;
+            if (e1 < lines)
+#pragma unroll
+                for (int g = 0; g < P; g += 4)
+                    if (e1 + g < lines)
+                        __builtin_amdgcn_global_load_lds(S + (size_t) (e1 + g) * 64 + lane * 4, ring + ((buf ^ 1) * P + g) * 64, 16, 0, 0);
+#pragma unroll
+            for (int g = 0; g < P; ++g)
+                if (e0 + g < lines) ring[(buf * P + g) * 64 + lane] = ring[(buf * P + g) * 64 + lane] * 1.0001f + 1.0f;
+#pragma unroll
+            for (int g = 0; g < P; g += 4)
+                if (e0 + g < lines) {
+                    const f4 v = *reinterpret_cast<const f4 *>(ring + (buf * P + g) * 64 + lane * 4);
+                    *reinterpret_cast<f4 *>(S + (size_t) (e0 + g) * 64 + lane * 4) = v;
+                }
+            buf ^= 1;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int reps) {
     hipEvent_t a, b;
@@ -120,6 +200,31 @@ int main(int argc, char **argv) {
     RUN_LDS(16)
     RUN_LDS(24)
     RUN_LDS(32)
+#define RUN_WIDE(P)                                                                                               \
+    {                                                                                                             \
+        const size_t lds = (size_t) (THREADS / 64) * 2 * P * 256;                                                 \
+        CHECK(hipFuncSetAttribute((const void *) stream_lds_wide<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+        const double ms = time_ms([&] { hipLaunchKernelGGL(stream_lds_wide<P>, dim3(blocks), dim3(THREADS), lds, 0, slabs, lines, sweeps); }, 3); \
+        printf("LDS-DMA dwordx4 in, dwordx4 out, %2d lines per wave per buffer (%3zu KB LDS): %7.2f ms  %6.2f TB/s\n", P, lds / 1024, ms, bytes / ms / 1e9); \
+    }
+    RUN_WIDE(8)
+    RUN_WIDE(16)
+    RUN_WIDE(32)
+    float *slabs2 = nullptr;
+    CHECK(hipMalloc(&slabs2, words * 4));
+    CHECK(hipMemset(slabs2, 0, words * 4));
+#define RUN_PP(P, NT, IP)                                                                                         \
+    {                                                                                                             \
+        const size_t lds = (size_t) (THREADS / 64) * 2 * P * 256;                                                 \
+        CHECK(hipFuncSetAttribute((const void *) stream_lds_pp<P, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+        const double ms = time_ms([&] { hipLaunchKernelGGL((stream_lds_pp<P, NT>), dim3(blocks), dim3(THREADS), lds, 0, slabs, IP ? slabs : slabs2, lines, sweeps); }, 3); \
+        printf("LDS-DMA staging, %2d lines per buffer, %s, %s: %7.2f ms  %6.2f TB/s\n", P, IP ? "in place" : "ping-pong (read A, write B)", NT ? "non-temporal" : "default policy", ms, bytes / ms / 1e9); \
+    }
+    RUN_PP(16, false, true)
+    RUN_PP(16, false, false)
+    RUN_PP(16, true, true)
+    RUN_PP(16, true, false)
+    CHECK(hipFree(slabs2));
     CHECK(hipFree(slabs));
     return 0;
 }

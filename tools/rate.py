@@ -31,13 +31,25 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--matrix", default=os.path.join(ROOT, "data", "H05.txt"))
     ap.add_argument("--synthetic", type=int, nargs=4, metavar=("M", "N", "DV", "DC"), default=None)
+    ap.add_argument("--qc", type=int, nargs=3, metavar=("MB", "NB", "Z"), default=None,
+                    help="all-ones MB x NB protograph of Z x Z cyclic shifts (shift = (3r + 7c) mod Z): a structured code whose variable sweep "
+                         "walks the message lines in a few sequential streams")
     ap.add_argument("--tag", default="")
     a = ap.parse_args()
     import numpy as np
     import torch
     import acg_alp_ldpc_amd as A
     from acg_alp_ldpc_amd._lib import McCfg, check, lib
-    if a.synthetic:
+    if a.qc:
+        mb, nb, Z = a.qc
+        Hd = np.zeros((mb * Z, nb * Z), dtype=np.uint8)
+        k = np.arange(Z)
+        for r in range(mb):
+            for c in range(nb):
+                Hd[r * Z + k, c * Z + (k + 3 * r + 7 * c) % Z] = 1
+        H = A.ParityCheckMatrix(Hd)
+        cws = np.zeros((1, nb * Z), dtype=np.uint8)
+    elif a.synthetic:
         m, n, dv, dc = a.synthetic
         H = A.ParityCheckMatrix(A.regular_ldpc(m, n, dv, dc, seed=1))
         cws = np.zeros((1, n), dtype=np.uint8)
