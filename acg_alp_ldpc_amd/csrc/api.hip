@@ -858,7 +858,7 @@ static int ensure_pipe(acg_ldpc_decoder *d, int64_t chunk, size_t y_bytes) {
             HIP_OK(hipEventCreateWithFlags(&d->pipe->done[b], hipEventDisableTiming));
         }
         const unsigned hc = std::thread::hardware_concurrency();
-        d->pipe->pool = new HostPool((int) std::max(2u, std::min(8u, hc ? hc / 2 : 2u)));
+        d->pipe->pool = new HostPool((int) std::max(2u, std::min(16u, hc ? hc / 2 : 2u)));
     }
     HostPipe &P = *d->pipe;
     if (chunk <= P.chunk && y_bytes <= P.y_bytes) return 0;

@@ -87,18 +87,23 @@ class Decoder:
             return np.zeros(0, dtype=np.uint8), False  # {TCodeword(), false}, bp.h:198
         return bits[0], bool(ok[0])
 
-    def decode_batch(self, H, Y, snr):
+    def decode_batch(self, H, Y, snr, out=None):
         """Y: frames x n channel symbols.  float64 (default): the reference's exact LLRs; a float32 array travels as
-        float32 (half the PCIe bytes, acg_ldpc_decode_batch_f32)."""
+        float32 (half the PCIe bytes, acg_ldpc_decode_batch_f32).  out = (bits, ok, iters) reuses caller arrays."""
         h, code = self.handle(H)
         f32 = isinstance(Y, np.ndarray) and Y.dtype == np.float32
         Y = np.ascontiguousarray(Y, dtype=np.float32 if f32 else np.float64)
         if Y.ndim != 2 or Y.shape[1] != code.n:
             raise ValueError("Y must be frames x n")
         F = Y.shape[0]
-        bits = np.empty((F, code.n), dtype=np.uint8)
-        ok = np.empty(F, dtype=np.uint8)
-        iters = np.empty(F, dtype=np.int32)
+        if out is not None:
+            bits, ok, iters = out
+            assert bits.shape == (F, code.n) and bits.dtype == np.uint8 and bits.flags.c_contiguous
+            assert ok.shape == (F,) and ok.dtype == np.uint8 and iters.shape == (F,) and iters.dtype == np.int32
+        else:
+            bits = np.empty((F, code.n), dtype=np.uint8)
+            ok = np.empty(F, dtype=np.uint8)
+            iters = np.empty(F, dtype=np.int32)
         fn = lib().acg_ldpc_decode_batch_f32 if f32 else lib().acg_ldpc_decode_batch
         check(fn(h, Y.ctypes.data, F, float(snr), bits.ctypes.data, ok.ctypes.data, iters.ctypes.data))
         return bits, ok, iters

@@ -52,7 +52,7 @@ CYC_VALU = 2.0
 CYC_TRANS = 8.0            # v_exp_f32 / v_log_f32 alone (quarter rate); the mul+exp PAIR measures 10-12
 CYC_VALU_F64 = 4.0         # fp64 add / mul / fma / max: half rate
 
-PROBE_ITEMS = ("bp_fused", "bp_streamed", "ms_streamed", "qpadmm", "c5_block_ms", "c5_streamed_ms")
+PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "qpadmm", "c5_block_ms", "c5_streamed_ms")
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
               ("write", ["WRITE_SIZE", "GRBM_GUI_ACTIVE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE",
@@ -347,7 +347,8 @@ def mc_leg(rig, H, cws, ctor, snr, F, steps):
         v = [x + int(y) for x, y in zip(v, r.as_vector())]
     v = rig.sum_ints(v)
     close_decoders(decs)
-    return {"value": rig.nshards * F * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+    kms = sum(r.kernel_ms for r in res.values()) / max(1, len(res))
+    return {"value": rig.nshards * F * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "kernel_ms": kms,
             "frames_per_gpu": F, "snr_db": snr, "fer": (v[2] - v[0]) / v[2], "pseudo_codewords": v[1],
             "mean_iters": v[6] / v[2], "raw_channel_errors_per_frame": v[3] / v[2]}
 
@@ -395,6 +396,12 @@ def pmc_probe_child(a):
     for name in items:
         if name.startswith("c5_"):
             continue
+        if name == "bp_mc":   # the Monte-Carlo kernel (AWGN + decode with the reference's stopping rule + classification)
+            decs = make_decoders(rig, T["bp_exit"])
+            for k in range(2):
+                A.run_experiment(decs[0], cws, H, a.snr, frames=a.frames, noise="device", seed=1 + k)
+            close_decoders(decs)
+            continue
         decs = make_decoders(rig, T[name])
         b.gen_noise(decs, a.snr)
         for _ in range(2):
@@ -418,9 +425,10 @@ def pmc_probe_child(a):
 
 
 PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
-    "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false", 0), "bp_streamed": ("bp_streamed_kernel<float, 0>", 0),
-    "ms_streamed": ("bp_streamed_kernel<float, 1>", 0), "qpadmm": ("admm_block_kernel<double, false", 0),
-    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false", 0), "c5_streamed_ms": ("bp_streamed_kernel<float, 1>", 1),
+    "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false", 1),
+    "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false>", 0),
+    "ms_streamed": ("bp_streamed_ring_kernel<1, false>", 0), "qpadmm": ("admm_block_kernel<double, false", 0),
+    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true>", 0),
 }
 
 
@@ -536,22 +544,27 @@ def roofline_fused(c, src, kms, F, bpf, fp64=False):
               "lds_bank_conflict_share": (c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
               "wave_wait_share": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
               "valu_insts_per_launch": nv, "trans_insts_per_launch": nt, "f64_arith_insts_per_launch": n64,
-              "model": "VALU: (%s x non-transcendental + %g x transcendental wave-instructions) / (1024 SIMDs x 2.4 GHz x kernel time)%s; "
+              "model": "VALU: (%s x other + %g x transcendental wave-instructions) / (1024 SIMDs x 2.4 GHz x kernel time)%s; "
                        "LDS: SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x kernel time); nominal clock, so both are lower bounds of the "
-                       "utilisation at the clock actually sustained" % (("%g" % (CYC_VALU_F64 if fp64 else CYC_VALU)), CYC_TRANS,
+                       "utilisation at the clock actually sustained" % (("%g" % (CYC_VALU if (not fp64 or n64 is not None) else CYC_VALU_F64)), CYC_TRANS,
                                                                        (" — fp64 add/mul/fma (SQ_INSTS_VALU_*_F64) at 4 cycles, everything else at 2" if n64 is not None else
                                                                         " — every VALU op priced as fp64 (upper bound)") if fp64 else "")})
     return r
 
 
-def roofline_hbm(c, src, kms, F, bpf):
+def roofline_hbm(c, src, kms, F, bpf, working_set=None):
     achieved = F * bpf / (kms * 1e-3) / 1e9
     traffic = None
     if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         traffic = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_over_algorithmic": (traffic / (F * bpf)) if traffic else None, "kernel_ms": kms,
-            "bytes_per_frame": bpf, "counters_from": src,
+            "bytes_per_frame": bpf, "counters_from": src, "slab_working_set_bytes": working_set,
+            "infinity_cache_resident": (working_set <= (256 << 20)) if working_set else None,
+            "note": ("the message slabs of all resident workgroups (%.0f MB) fit in the 256 MiB Infinity Cache: the traffic counted here is "
+                     "L2 <-> fabric traffic, most of which never reaches the HBM stacks" % (working_set / 1e6)) if working_set and working_set <= (256 << 20)
+                    else ("slabs (%.0f MB) exceed the Infinity Cache: HBM traffic.  Measured ceiling of the bare access pattern (read a 256-byte "
+                          "line, write it back) on HBM-resident slabs: 5.0-5.5 TB/s (profiles/r02_slab_stream.txt)" % (working_set / 1e6)) if working_set else None,
             "model": "SURVEY 8(d) streamed model: %d B/frame x %d frames / %.3f ms mean kernel time; the messages live in HBM, "
                      "so this IS memory traffic (traffic = FETCH_SIZE x2 + WRITE_SIZE of a rocprofv3 pass over the same launch)" % (bpf, F, kms)}
 
@@ -643,7 +656,11 @@ def main():
         ee = {}
         for snr in (a.snr, 2.0):
             r = decode_leg(rig, batch, T["bp_exit"], snr, ss, 1)
-            r["streamed_equiv_frac"] = F * bp_bytes_per_frame(n, E, r["mean_iters"]) / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if snr == a.snr:
+                c, src = pmc_lookup(pmc, "bp_exit")
+                r["roofline"] = roofline_fused(c, src, r["kernel_ms"], F, bp_bytes_per_frame(n, E, r["mean_iters"]))
+            else:
+                r["streamed_equiv_frac"] = F * bp_bytes_per_frame(n, E, r["mean_iters"]) / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             ee["%+.1fdB" % snr] = r
         out["early_exit"] = ee
         # ---- north_star's named variant: normalised min-sum (NOT in the reference: parity unpinned) --
@@ -655,7 +672,7 @@ def main():
         for key, item in (("sum_product", "bp_streamed"), ("minsum_0.75", "ms_streamed")):
             r = decode_leg(rig, batch, T[item], a.snr, ss, 1)
             c, src = pmc_lookup(pmc, item)
-            r["roofline"] = roofline_hbm(c, src, r["kernel_ms"], F, bpf)
+            r["roofline"] = roofline_hbm(c, src, r["kernel_ms"], F, bpf, working_set=r["layout"]["grid_blocks"] * ((E + n) * 256 + n * 16))
             st[key] = r
         st["workload"] = "configs[1] on the streamed engine: same frames, 50 iterations fixed, messages in HBM"
         out["streamed"] = st
@@ -670,10 +687,13 @@ def main():
                                          % (a.alpha, a.mu, F, a.snr), "dtype": "f64",
                              "fixed_100_sweeps": q_fixed, "residual_exit_1e-5": q_exit}
         # ---- Monte-Carlo mode: the metric as SURVEY §8(d) defines it -------------------------------------
+        mc_main = mc_leg(rig, H, cws, T["bp_exit"], a.snr, F, ss)
+        c, src = pmc_lookup(pmc, "bp_mc")
+        mc_main["roofline"] = roofline_fused(c, src, mc_main["kernel_ms"], F, bp_bytes_per_frame(n, E, mc_main["mean_iters"]))
         out["monte_carlo"] = {
             "definition": "acg_ldpc_mc_run: AWGN generated on the device, decode with the reference's stopping rule, "
                           "classification against the sent word, D2H of the seven counters; wall time of the calls",
-            "bp50_%+.1fdB" % a.snr: mc_leg(rig, H, cws, T["bp_exit"], a.snr, F, ss),
+            "bp50_%+.1fdB" % a.snr: mc_main,
             "bp50_+2.0dB": mc_leg(rig, H, cws, T["bp_exit"], 2.0, F, ss),
             "qpadmm100_%+.1fdB" % a.snr: mc_leg(rig, H, cws, T["qpadmm_exit"], a.snr, F // 4, ss),
         }
@@ -690,7 +710,8 @@ def main():
             r = decode_leg(rig, b5, T[item], 2.0, ss, 1)
             c, src = pmc_lookup(pmc, item)
             if hbm:
-                r["roofline"] = roofline_hbm(c, src, r["kernel_ms"], a.c5_frames, bpf5)
+                r["roofline"] = roofline_hbm(c, src, r["kernel_ms"], a.c5_frames, bpf5,
+                                             working_set=min(r["layout"]["grid_blocks"], (a.c5_frames + 63) // 64) * ((H5.E + H5.n) * 256 + H5.n * 16))
             elif c or item == "c5_block_ms":
                 r["roofline"] = roofline_fused(c, src, r["kernel_ms"], a.c5_frames, bpf5)
             c5[key] = r

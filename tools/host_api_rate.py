@@ -19,11 +19,12 @@ y = (1 - 2 * cws[np.arange(F) % 4096].astype(np.float64)) + np.sqrt(A.llr_varian
 y32 = y.astype(np.float32)
 for name, dec in (("BP-50", A.BeliefPropagationDecoder(50)), ("QP-ADMM-100", A.QPADMMDecoder(1.95, 0.5, 100, 1e-5))):
     dec.decode_batch(H, y[:1024], snr)
+    out = (np.zeros((F, H.n), np.uint8), np.zeros(F, np.uint8), np.zeros(F, np.int32))   # touched once: no page faults in the timed calls
     for arr, what in ((y, "float64 symbols (exact LLRs)"), (y32, "float32 symbols")):
         best = 1e9
         for _ in range(3):
             t = time.time()
-            bits, ok, it = dec.decode_batch(H, arr, snr)
+            bits, ok, it = dec.decode_batch(H, arr, snr, out=out)
             best = min(best, time.time() - t)
         print("%s host API, %s: %d frames in %.3f s = %.2f M frames/s (H2D %.0f MB, D2H-side %.0f MB of bytes), ok=%.4f"
               % (name, what, F, best, F / best / 1e6, arr.nbytes / 1e6, bits.nbytes / 1e6, ok.mean()))
