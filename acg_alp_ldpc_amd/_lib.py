@@ -37,7 +37,7 @@ class McResult(C.Structure):
 
 
 ALGO_BP, ALGO_MINSUM, ALGO_QPADMM = 0, 1, 2
-PREC_DEFAULT, PREC_F64, PREC_F32 = 0, 1, 2
+PREC_DEFAULT, PREC_F64, PREC_F32, PREC_F16 = 0, 1, 2, 3
 NOISE_DEVICE_PHILOX, NOISE_HOST_MT19937 = 0, 1
 ENGINE_AUTO, ENGINE_FUSED, ENGINE_STREAMED = 0, 1, 2
 

@@ -855,6 +855,11 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     d->alpha = p.alpha;
     d->mu = p.mu;
     d->eps = p.eps_stop;
+    if (p.precision == ACG_LDPC_PREC_F16) {
+        err = "ACG_LDPC_PREC_F16 exists for the fused min-sum decoder only";
+        delete d;
+        return nullptr;
+    }
     d->f32 = (p.precision == ACG_LDPC_PREC_F32) ? 1 : 0;
     int L = p.lanes_per_frame ? p.lanes_per_frame : 64;
     // auto / 256: one workgroup (128, 192 or 256 threads) per frame when the problem has at most 4 passes of it.

@@ -36,6 +36,7 @@ hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t firs
 const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, bool idxreg);
 const void *bp_kernel_ptr_dbg(int f64, int L);
 const void *bp_block_kernel_ptr_dbg(int f64);
+const void *bp_pair_kernel_ptr(int L, bool regular);
 const void *bp_streamed_ptr(int algo, int f64);
 const void *bp_streamed_ring_ptr(int algo, bool nt);
 hipError_t bp_streamed_ring_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid, hipStream_t s);
@@ -197,6 +198,7 @@ struct acg_ldpc_decoder {
     const void *kernel[2] = {nullptr, nullptr};
     size_t lds_block = 0;
     int variant = -1;       // wave-group kernels: 0 / 1 / 2 (see bp_inst_*.hip); -1 = workgroup-per-frame
+    bool pair = false;      // ACG_LDPC_PREC_F16: two frames per workgroup, packed half-precision messages (bp_pair.hip)
     bool blk_idxlds = false, blk_idxreg = false;
     // streamed BP engine
     bool streamed = false;
@@ -459,9 +461,20 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
         set_error("unknown engine");
         return 1;
     }
+    const bool pair = (d->p.precision == ACG_LDPC_PREC_F16);
+    if (pair) {
+        if (d->p.algo != ACG_LDPC_BP_MINSUM || d->p.engine == ACG_LDPC_ENGINE_STREAMED) {
+            set_error("ACG_LDPC_PREC_F16 exists for the fused min-sum decoder only (the reference's sum-product needs fp32/fp64 messages)");
+            return 3;
+        }
+        if (c.max_cdeg > 8 || c.max_vdeg > 4 || c.n > 12 * 1024) {
+            set_error("ACG_LDPC_PREC_F16 needs check degree <= 8, variable degree <= 4 and n <= 12288");
+            return 3;
+        }
+    }
     if (d->p.engine == ACG_LDPC_ENGINE_STREAMED) return decoder_setup_streamed(d);
     d->maxd = std::max(c.max_cdeg, c.max_vdeg);
-    {
+    if (!pair) {
         // does one frame fit in LDS?  (message words incl. padding at the smallest group size + LLRs)
         const size_t ts0 = (d->p.precision == ACG_LDPC_PREC_F64) ? 8 : 4;
         // (LLRs sit in registers for up to 12 passes of the group size, i.e. n <= 12288 in workgroup mode)
@@ -484,7 +497,15 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     // Workgroup-per-frame mode (bp_block.hip) for codes whose message array leaves room for only a few
     // wavefront-sized frames per CU: the same LDS then feeds 4-16x as many wavefronts.
     bool blockmode = (L == 256 || L == 1024);
-    if (L == 0 && d->maxd <= 8) {
+    if (pair) {  // always one workgroup per frame pair: 256 threads when the variables fit in 12 passes of them, else 1024
+        if (L != 0 && L != 256 && L != 1024) {
+            set_error("ACG_LDPC_PREC_F16: lanes_per_frame must be 0, 256 or 1024");
+            return 3;
+        }
+        if (L == 0) L = (c.n <= 12 * 256) ? 256 : 1024;
+        blockmode = true;
+    }
+    if (!pair && L == 0 && d->maxd <= 8) {
         const size_t ts0 = d->f64 ? 8 : 4;
         const size_t wave_frame = ((size_t) c.E + 64 + ((size_t) c.n > 12 * 64 ? (size_t) c.n : 0)) * ts0;  // rough, L = 64
         const int waves_cu = (int) std::min<size_t>(32, (160 * 1024) / std::max<size_t>(wave_frame, 1));
@@ -526,6 +547,7 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     const bool llr_regs = blockmode || ((d->maxd <= 8) && (lay.n_vpass <= 12));
     const int llr_words = llr_regs ? 0 : lay.n_vpass * L;
     size_t per_frame = (size_t) (lay.a_words + llr_words) * ts + (size_t) nwords * 4;
+    if (pair) per_frame = (size_t) lay.a_words * 4 + 2 * (size_t) nwords * 4;  // one 32-bit word per edge for TWO frames
     per_frame = (per_frame + 15) & ~(size_t) 15;
 
     BpTables &t = d->tab;
@@ -586,6 +608,29 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
         d->block = L;
         d->frames_per_block = 1;
         d->lds_block = per_frame + t.idx_lds_bytes;
+        if (pair) {
+            d->pair = true;
+            d->frames_per_block = 2;
+            d->lds_block = per_frame;
+            t.idx_lds_bytes = 0;
+            // regular code (one check degree, one variable degree): the instance with fully unrolled passes
+            bool regular = c.max_cdeg >= 1 && c.max_vdeg >= 1;
+            for (int i = 0; i < c.m && regular; i++) regular = (c.row_ptr[i + 1] - c.row_ptr[i] == c.max_cdeg);
+            for (int j = 0; j < c.n && regular; j++) regular = (c.col_ptr[j + 1] - c.col_ptr[j] == c.max_vdeg);
+            const void *kp = bp_pair_kernel_ptr(L, regular);
+            if (!kp) {
+                set_error("no paired-frame kernel instance for this configuration");
+                return 3;
+            }
+            if (d->lds_block > 64 * 1024)
+                HIP_OK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block));
+            int occ = 0;
+            HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, d->block, d->lds_block));
+            d->kernel[0] = kp;
+            d->kernel[1] = nullptr;  // Monte-Carlo runs go AWGN kernel -> decode -> classify kernel
+            d->grid_cap[0] = d->grid_cap[1] = std::max(occ, 1) * d->cu_count;
+            return 0;
+        }
         const int algo_b = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
         for (int mc = 0; mc < 2; mc++) {
             // index table too large for LDS and variable degree <= 4: keep it in registers (decode kernel only)
@@ -1136,7 +1181,7 @@ int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc
     int rc = 0;
     if (cfg->noise == ACG_LDPC_NOISE_HOST_MT19937) {
         rc = mc_run_host_noise(d, cfg, res);
-    } else if (d->streamed || (d->admm && admm_device_unfused_mc(d->admm, nullptr, nullptr))) {
+    } else if (d->streamed || d->pair || (d->admm && admm_device_unfused_mc(d->admm, nullptr, nullptr))) {
         // AWGN kernel -> decode -> classify kernel, in bounded chunks, all on the device.  Used by the streamed BP
         // engine (no in-kernel generator) and by the workgroup-per-frame QP-ADMM kernel, whose fused Monte-Carlo
         // variant needs 156 VGPRs (3 waves/SIMD) against 117 (4) for the plain decode: 1.6 M vs 2.7 M frames/s.

@@ -52,7 +52,7 @@ CYC_VALU = 2.0
 CYC_TRANS = 8.0            # v_exp_f32 / v_log_f32 alone (quarter rate); the mul+exp PAIR measures 10-12
 CYC_VALU_F64 = 4.0         # fp64 add / mul / fma / max: half rate
 
-PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "qpadmm", "c5_block_ms", "c5_streamed_ms")
+PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "qpadmm", "c5_block_ms", "c5_pair_f16_ms", "c5_streamed_ms")
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
               ("write", ["WRITE_SIZE", "GRBM_GUI_ACTIVE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE",
@@ -368,6 +368,7 @@ def ctor_table(A, a):
         "qpadmm_exit": lambda dev: A.QPADMMDecoder(a.alpha, a.mu, 100, 1e-5, device=dev),
         "c5_block_ms": lambda dev: A.MinSumDecoder(50, 0.75, early_exit=False, device=dev),
         "c5_block_spa": lambda dev: A.BeliefPropagationDecoder(50, early_exit=False, device=dev),
+        "c5_pair_f16_ms": lambda dev: A.MinSumDecoder(50, 0.75, early_exit=False, device=dev, precision=A.PREC_F16),
         "c5_streamed_ms": lambda dev: A.MinSumDecoder(50, 0.75, early_exit=False, device=dev, engine=eng_s),
     }
 
@@ -428,7 +429,7 @@ PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position am
     "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false", 1),
     "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false>", 0),
     "ms_streamed": ("bp_streamed_ring_kernel<1, false>", 0), "qpadmm": ("admm_block_kernel<double, false", 0),
-    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true>", 0),
+    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true>", 0),
 }
 
 
@@ -705,14 +706,14 @@ def main():
         bpf5 = bp_bytes_per_frame(H5.n, H5.E, 50)
         c5 = {"workload": "configs[4]: synthetic (3,6)-regular %dx%d (E=%d), 50 iterations FIXED, %d frames per GPU per step "
                           "at +2.0 dB, all-zero codeword" % (H5.m, H5.n, H5.E, a.c5_frames)}
-        for key, item, hbm in (("fused_block_minsum", "c5_block_ms", False), ("fused_block_sum_product", "c5_block_spa", False),
-                               ("streamed_minsum", "c5_streamed_ms", True)):
+        for key, item, hbm in (("fused_block_minsum", "c5_block_ms", False), ("fused_pair_f16_minsum", "c5_pair_f16_ms", False),
+                               ("fused_block_sum_product", "c5_block_spa", False), ("streamed_minsum", "c5_streamed_ms", True)):
             r = decode_leg(rig, b5, T[item], 2.0, ss, 1)
             c, src = pmc_lookup(pmc, item)
             if hbm:
                 r["roofline"] = roofline_hbm(c, src, r["kernel_ms"], a.c5_frames, bpf5,
                                              working_set=min(r["layout"]["grid_blocks"], (a.c5_frames + 63) // 64) * ((H5.E + H5.n) * 256 + H5.n * 16))
-            elif c or item == "c5_block_ms":
+            elif c or item in ("c5_block_ms", "c5_pair_f16_ms"):
                 r["roofline"] = roofline_fused(c, src, r["kernel_ms"], a.c5_frames, bpf5)
             c5[key] = r
         out["configs[4]"] = c5

@@ -44,7 +44,10 @@ enum {
 enum {
     ACG_LDPC_PREC_DEFAULT = 0, /* BP: fp32 messages; QP-ADMM: fp64 */
     ACG_LDPC_PREC_F64 = 1,     /* everything fp64 */
-    ACG_LDPC_PREC_F32 = 2      /* everything fp32 (QP-ADMM then matches FER only) */
+    ACG_LDPC_PREC_F32 = 2,     /* everything fp32 (QP-ADMM then matches FER only) */
+    ACG_LDPC_PREC_F16 = 3      /* min-sum only (build-added variant, parity unpinned): half-precision messages, two frames
+                                  per workgroup sharing every LDS word, index and barrier — for codes whose messages fill
+                                  the LDS of a CU (check degree <= 8, variable degree <= 4, n <= 12288) */
 };
 
 /* BP engine selector */

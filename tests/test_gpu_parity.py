@@ -517,6 +517,65 @@ def test_config5_synthetic_regular_code(A, oracle):
     assert r.sum_hamming == r.sum_hamming_ok + r.sum_hamming_wrong
 
 
+def test_pair_f16_minsum_kernels(A, oracle):
+    """precision = PREC_F16: two frames per workgroup, packed half-precision min-sum messages (bp_pair.hip).  Min-sum is
+    not in the reference (parity unpinned) and half precision moves knife-edge frames, so the bar is the one of
+    the fp32 min-sum kernels, loosened to what 10-bit magnitudes allow: at a comfortable SNR every frame decodes to the
+    oracle's word (exit iteration within 2 sweeps); near the threshold the FER stays within 0.06 of the fp32 kernel's;
+    ragged batches (odd frame counts), both workgroup sizes, regular and irregular codes; sum-product / QP-ADMM refuse
+    the precision."""
+    # (a) BASELINE configs[4] code: regular instance, 1024 threads per frame pair
+    Hm = A.regular_ldpc(5000, 10000, 3, 6, seed=1)
+    H = A.ParityCheckMatrix(Hm)
+    rng = np.random.default_rng(3)
+    snr = 2.0
+    y = 1.0 + np.sqrt(A.llr_variance(snr)) * rng.standard_normal((13, 10000))      # odd count: the last pair is half empty
+    ob, ook, oit = oracle.minsum_decode(Hm, y, snr, 50, 0.75, threads=8)
+    for ee in (True, False):
+        dec = A.MinSumDecoder(50, 0.75, precision=A.PREC_F16, early_exit=ee)
+        assert dec.layout(H) == dict(dec.layout(H), lanes_per_frame=1024, frames_per_block=2)
+        bits, ok, it = dec.decode_batch(H, y, snr)
+        assert (ok == ook).all() and (bits == ob).all() and np.abs(it - oit).max() <= 2, (ee, it, oit)
+        r = A.run_experiment(dec, None, H, snr, frames=2049, noise="device", seed=3)     # AWGN kernel -> decode -> classify
+        dec.close()
+        assert r.total == 2049 and r.pseudo == 0 and r.correct >= 2046, r
+    y2 = 1.0 + np.sqrt(A.llr_variance(-1.6)) * rng.standard_normal((256, 10000))
+    fers = []
+    for prec in (A.PREC_DEFAULT, A.PREC_F16):
+        dec = A.MinSumDecoder(50, 0.75, precision=prec)
+        b2, k2, i2 = dec.decode_batch(H, y2, -1.6)
+        dec.close()
+        assert not b2[k2 == 1].any()                     # whatever converges, converges to the sent (all-zero) word
+        fers.append(1 - k2.mean())
+    assert 0.02 < fers[0] < 0.9 and abs(fers[0] - fers[1]) < 0.06, fers
+    # (b) 256 threads per pair: a regular (3,6) 1500 x 3000 code and an irregular code (variable degree 2..4, check degree 4..8)
+    Hr = A.regular_ldpc(1500, 3000, 3, 6, seed=5)
+    Hi = np.zeros((300, 600), np.uint8)
+    r2 = np.random.default_rng(8)
+    for v in range(600):
+        Hi[r2.choice(300, size=2 + (v % 3), replace=False), v] = 1
+    Hi = Hi[(Hi.sum(1) >= 2)]
+    for Hx in (Hr, Hi):
+        if Hx.sum(1).max() > 8:
+            Hx = Hx.copy()
+            for i in np.nonzero(Hx.sum(1) > 8)[0]:
+                Hx[i, np.nonzero(Hx[i])[0][8:]] = 0
+        Hc = A.ParityCheckMatrix(Hx)
+        yy = 1.0 + np.sqrt(A.llr_variance(4.0)) * rng.standard_normal((41, Hc.n))
+        ob, ook, oit = oracle.minsum_decode(Hx, yy, 4.0, 30, 0.75, threads=4)
+        dec = A.MinSumDecoder(30, 0.75, precision=A.PREC_F16)
+        assert dec.layout(Hc)["lanes_per_frame"] == 256
+        bits, ok, it = dec.decode_batch(Hc, yy, 4.0)
+        dec.close()
+        same = (ok == ook) & (bits == ob).all(axis=1)
+        assert same.mean() >= 0.95 and np.abs(it - oit)[same].max() <= 2, (same.mean(), Hc.m, Hc.n)
+    # (c) only min-sum has the half-precision variant
+    with pytest.raises(A.LdpcError):
+        A.BeliefPropagationDecoder(10, precision=A.PREC_F16).decode_batch(H, y[:1], snr)
+    with pytest.raises(A.LdpcError):
+        A.QPADMMDecoder(0.6, 1.0, 10, precision=A.PREC_F16).decode_batch(H, y[:1], snr)
+
+
 def test_config5_block_kernel_variants_agree_near_threshold(A, oracle):
     """The workgroup-per-frame instance used for the (3,6) 5000 x 10000 code (index table in registers, syndrome taken
     from the check sweep, bank-conflict placement) against the plain instance (ACG_BP_NO_IDXREG / ACG_BP_NO_PLACEMENT)

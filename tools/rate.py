@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--snr", type=float, default=-2.0)
     ap.add_argument("--exit", action="store_true", help="the reference's stopping rule instead of fixed work")
     ap.add_argument("--lanes", type=int, default=0)
-    ap.add_argument("--prec", choices=["default", "f32", "f64"], default="default")
+    ap.add_argument("--prec", choices=["default", "f32", "f64", "f16"], default="default")
     ap.add_argument("--alpha", type=float, default=1.95)
     ap.add_argument("--mu", type=float, default=0.5)
     ap.add_argument("--steps", type=int, default=5)
@@ -58,7 +58,7 @@ def main():
         G, ok = H.get_orthogonal()
         cws = A.gen_random_codewords(G, 8192, 239239239)
     eng = {"auto": A.ENGINE_AUTO, "fused": A.ENGINE_FUSED, "streamed": A.ENGINE_STREAMED}[a.engine]
-    prec = {"default": A.PREC_DEFAULT, "f32": A.PREC_F32, "f64": A.PREC_F64}[a.prec]
+    prec = {"default": A.PREC_DEFAULT, "f32": A.PREC_F32, "f64": A.PREC_F64, "f16": A.PREC_F16}[a.prec]
     t0 = time.time()
     if a.algo == "qpadmm":
         dec = A.QPADMMDecoder(a.alpha, a.mu, a.iters, 1e-5 if a.exit else 0.0, lanes_per_frame=a.lanes, precision=prec)
