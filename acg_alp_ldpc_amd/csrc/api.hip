@@ -1077,11 +1077,28 @@ float acg_ldpc_decoder_last_kernel_ms(acg_ldpc_decoder *d) {
 static int ensure_codewords(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg) {
     if (!cfg->codewords || cfg->n_codewords <= 0) return 0;
     // the device copy is keyed on the CONTENT of the host array (a pointer can be recycled for different words)
+    // (hashed 8 bytes at a time in four independent lanes: the byte-wise loop took 2.5 ms for 8192 x 280 codewords — more than
+    // an early-exit launch over a million frames — on every Monte-Carlo call)
     uint64_t h = 1469598103934665603ull;
     {
         const uint8_t *pb = cfg->codewords;
         const size_t nb = (size_t) cfg->n_codewords * (size_t) d->c.n;
-        for (size_t i = 0; i < nb; i++) h = (h ^ (uint64_t) (pb[i] != 0)) * 1099511628211ull;
+        uint64_t hl[4] = {h, h ^ 0x9E3779B97F4A7C15ull, h ^ 0xC2B2AE3D27D4EB4Full, h ^ 0x165667B19E3779F9ull};
+        size_t i = 0;
+        for (; i + 32 <= nb; i += 32)
+            for (int k = 0; k < 4; k++) {
+                uint64_t w;
+                std::memcpy(&w, pb + i + 8 * k, 8);
+                // any non-zero byte means bit 1 (the reference reads '1' cells, others are 0): normalise every byte to 0 / 1
+                w |= w >> 4;
+                w |= w >> 2;
+                w |= w >> 1;
+                w &= 0x0101010101010101ull;
+                hl[k] = (hl[k] ^ w) * 1099511628211ull;
+                hl[k] ^= hl[k] >> 29;
+            }
+        for (; i < nb; i++) hl[0] = (hl[0] ^ (uint64_t) (pb[i] != 0)) * 1099511628211ull;
+        h = ((hl[0] * 31 + hl[1]) * 31 + hl[2]) * 31 + hl[3];
     }
     if (d->cw_dev && d->cw_hash == h && d->cw_count == cfg->n_codewords) return 0;
     if (d->cw_dev) (void) hipFree(d->cw_dev);
