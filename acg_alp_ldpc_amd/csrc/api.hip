@@ -811,6 +811,12 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
     if (d->streamed && d->last_slot >= 0 && d->last_stream != s) HIP_OK(hipStreamWaitEvent(s, d->ring_ev[d->last_slot], 0));
     a.work_counter = d->work_ring + slot;
     HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
+#ifdef ACG_BLOCK_STAMPS
+    static unsigned long long *stamp_buf = nullptr;  // developer build only (tools/ab_variant.sh ... -DACG_BLOCK_STAMPS)
+    if (!stamp_buf) HIP_OK(hipMalloc((void **) &stamp_buf, 16 * 5 * sizeof(unsigned long long)));
+    HIP_OK(hipMemsetAsync(stamp_buf, 0, 16 * 5 * sizeof(unsigned long long), s));
+    a.dbg_post = stamp_buf;
+#endif
     HIP_OK(hipEventRecord(d->ev0, s));
     if (d->admm) {
         std::string err;
@@ -843,6 +849,18 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         HIP_OK(bp_launch(d->kernel[mc], d->tab, a, grid, d->block, d->lds_block, s));
     }
     HIP_OK(hipEventRecord(d->ev1, s));
+#ifdef ACG_BLOCK_STAMPS
+    if (!d->admm && !d->streamed && getenv("ACG_STAMPS")) {
+        unsigned long long h[16 * 5];
+        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(hipMemcpy(h, stamp_buf, sizeof(h), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 16; w++)
+            if (h[w * 5 + 4])
+                fprintf(stderr, "[stamps] wave %2d: per sweep: check %6.0f  barrier %6.0f  var %6.0f  barrier %6.0f cycles (%llu sweeps)\n", w,
+                        (double) h[w * 5] / h[w * 5 + 4], (double) h[w * 5 + 1] / h[w * 5 + 4], (double) h[w * 5 + 2] / h[w * 5 + 4],
+                        (double) h[w * 5 + 3] / h[w * 5 + 4], h[w * 5 + 4]);
+    }
+#endif
     HIP_OK(hipEventRecord(d->ring_ev[slot], s));
     d->ring_used[slot] = true;
     d->last_slot = slot;

@@ -41,6 +41,9 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
     unsigned long long acc_correct = 0, acc_pseudo = 0, acc_total = 0, acc_ham = 0, acc_ham_ok = 0, acc_ham_wrong = 0, acc_iters = 0;
     // padding words and the zero cell are +0.0 for the whole launch
     for (int w = l; w < t.a_words; w += L) A[w] = (T) 0;
+#ifdef ACG_BLOCK_STAMPS
+    unsigned long long st_chk = 0, st_b1 = 0, st_var = 0, st_b2 = 0, st_n = 0;
+#endif
 
     for (;;) {
         __syncthreads();
@@ -103,6 +106,9 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
         core.var_init_phase(lr, true);  // bp.h:184 on empty mailboxes
         __syncthreads();
         // ---- sweeps (bp.h:186-197) -----------------------------------------------------------------------------
+#ifdef ACG_BLOCK_STAMPS
+        st_chk = st_b1 = st_var = st_b2 = st_n = 0;
+#endif
         int it = 0;
         bool latched = false;
         // decode instances (MERGED): the syndrome comes out of the check sweep and the hard decisions of my variables live
@@ -114,7 +120,18 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
             if (MERGED) {
                 // the check sweep reads every v->c word anyway: it also delivers the syndrome of the hard bits riding in
                 // them (no separate syndrome pass, one barrier less per sweep).  Its c->v output is wasted on the last trip.
+#ifdef ACG_BLOCK_STAMPS
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                const bool myb = core.check_phase_syndrome(true);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long t1 = __builtin_readcyclecounter();
+                bad = __syncthreads_or(myb ? 1 : 0) != 0;
+                const unsigned long long t2 = __builtin_readcyclecounter();
+                st_chk += t1 - t0;
+                st_b1 += t2 - t1;
+#else
                 bad = __syncthreads_or(core.check_phase_syndrome(true) ? 1 : 0) != 0;
+#endif
             } else {
                 bad = __syncthreads_or(core.syndrome_bad() ? 1 : 0) != 0;
             }
@@ -158,14 +175,30 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
             if (DBG && MERGED && it == a.max_iter - 1 && a.dbg_c2v)  // (the barrier inside __syncthreads_or ordered the sweep)
                 for (int w = l; w < t.a_words; w += L) reinterpret_cast<T *>(a.dbg_c2v)[(size_t) frame * t.a_words + w] = A[w];
             if (DBG) __syncthreads();
+#ifdef ACG_BLOCK_STAMPS
+            const unsigned long long t3 = __builtin_readcyclecounter();
+#endif
             if (MERGED) {
+                if (IDXREG) {
+#pragma unroll
+                    for (int i = 0; i < 2 * NVP; ++i) asm volatile("" : "+v"(ir[i]));  // see BpCore::var_phase_regs
+                }
                 hard = IDXREG ? core.var_phase_regs(lr, ir, true) : core.var_phase_hard(lr, true);
             } else {
                 core.check_phase(true);
                 __syncthreads();
                 core.var_phase(lr, true);
             }
+#ifdef ACG_BLOCK_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t4 = __builtin_readcyclecounter();
             __syncthreads();
+            st_var += t4 - t3;
+            st_b2 += __builtin_readcyclecounter() - t4;
+            st_n += 1;
+#else
+            __syncthreads();
+#endif
             if (DBG && it == a.max_iter - 1 && a.dbg_v2c) {
                 for (int w = l; w < t.a_words; w += L) reinterpret_cast<T *>(a.dbg_v2c)[(size_t) frame * t.a_words + w] = A[w];
                 for (int p = 0; p < t.n_vpass; ++p)
@@ -175,6 +208,13 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
             it += 1;
         }
     }
+#ifdef ACG_BLOCK_STAMPS
+        // developer build: cycles of the LAST frame of this workgroup, per wavefront: {check sweep, barrier, variable sweep, barrier, sweeps}
+        if (a.dbg_post && blockIdx.x == 0 && (l & 63) == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dbg_post) + (size_t) (l >> 6) * 5;
+            o[0] = st_chk; o[1] = st_b1; o[2] = st_var; o[3] = st_b2; o[4] = st_n;
+        }
+#endif
     if (MC && l == 0 && acc_total) {
         atomicAdd(&a.counters[MC_CORRECT], acc_correct);
         atomicAdd(&a.counters[MC_PSEUDO], acc_pseudo);
