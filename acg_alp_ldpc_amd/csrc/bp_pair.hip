@@ -74,54 +74,6 @@ __device__ __forceinline__ u32 pair_check(u32 *__restrict__ Ap, int slot, const 
     return S;
 }
 
-// TWO check passes at once with the two dependency chains interleaved instruction by instruction.  The stamps of the fp32
-// workgroup kernel show what the sweep is short of: with four wavefronts per SIMD, each a single chain of
-// dependent min / max / select operations, the VALU issues in under half of its cycles; two independent chains per wavefront
-// fill the slots.  Only for uniform check degree (no padding inside a pass; slot0 / slot1 may still lie beyond the last check).
-template <int D, int L>
-__device__ __forceinline__ u32 pair_check2(u32 *__restrict__ Ap0, u32 *__restrict__ Ap1, int slot0, int slot1, int m, h2 scale) {
-    u32 x[2][D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        x[0][j] = Ap0[j * L];
-        x[1][j] = Ap1[j * L];
-    }
-    u32 S[2] = {0u, 0u};
-    u32 a[2][D];
-    h2 m1[2] = {as_h2(INF2), as_h2(INF2)}, m2[2] = {as_h2(INF2), as_h2(INF2)};
-#pragma unroll
-    for (int j = 0; j < D; ++j)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            S[c] ^= x[c][j];
-            a[c][j] = x[c][j] & MAG2;
-            const h2 aj = as_h2(a[c][j]);
-            const h2 t = __builtin_elementwise_max(m1[c], aj);
-            m1[c] = __builtin_elementwise_min(m1[c], aj);
-            m2[c] = __builtin_elementwise_min(m2[c], t);
-        }
-    u32 ob[2][D];
-#pragma unroll
-    for (int j = 0; j < D; ++j)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const u32 u1 = as_u(m1[c]), u2 = as_u(m2[c]);
-            const u32 eq = pk_sub_u16(pk_min_u16(a[c][j] ^ u1, LSB2), LSB2);
-            const u32 o = (u2 & eq) | (u1 & ~eq);
-            const u32 sc = as_u(as_h2(o) * scale);
-            ob[c][j] = (sc & 0x7FFF7FFFu) | ((S[c] ^ x[c][j]) & SIGN2);
-        }
-    if (slot0 < m) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) Ap0[j * L] = ob[0][j];
-    }
-    if (slot1 < m) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) Ap1[j * L] = ob[1][j];
-    }
-    return S[0] | S[1];
-}
-
 // One variable pass with the D message positions known; returns the posterior hard decisions (bit 0 / bit 16)
 template <int D>
 __device__ __forceinline__ u32 pair_var(u32 *__restrict__ A, const int (&pos)[D], h2 llr, int slot, const int *cnt) {
@@ -261,13 +213,8 @@ __global__ void __launch_bounds__(L) bp_pair_kernel(const BpTables t, const Deco
         for (;;) {
             u32 acc = 0;
             if constexpr (uniform_c) {
-#define ACG_CALL(D)                                                                                                  \
-    {                                                                                                                \
-        int p = 0;                                                                                                   \
-        for (; p + 1 < t.n_cpass; p += 2)                                                                            \
-            acc |= pair_check2<D, L>(A + p * (D * L) + l, A + (p + 1) * (D * L) + l, p * L + l, (p + 1) * L + l, t.m, scale); \
-        if (p < t.n_cpass) acc |= pair_check<D, L, true>(A + p * (D * L) + l, p * L + l, ccnt + (D - 1), scale);     \
-    }
+#define ACG_CALL(D) \
+    for (int p = 0; p < t.n_cpass; ++p) acc |= pair_check<D, L, true>(A + p * (D * L) + l, p * L + l, ccnt + (D - 1), scale)
                 ACG_PAIR_CSWITCH(cd0, ACG_CALL)
 #undef ACG_CALL
             } else {
