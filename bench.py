@@ -439,7 +439,7 @@ def pmc_one_pass(a, tag, ctrs, left, env, out):
     import glob
     import signal
     tmp = tempfile.mkdtemp(prefix="acg_pmc_%s_" % tag, dir="/tmp")
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", tmp, "--",
+    cmd = [os.environ.get("ACG_BENCH_ROCPROF", "rocprofv3"), "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", tmp, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-probe", "--frames", str(a.frames), "--c5-frames",
            str(a.c5_frames), "--snr", str(a.snr), "--iters", str(a.iters), "--alpha", str(a.alpha), "--mu", str(a.mu),
            "--matrix", a.matrix, "--lanes", str(a.lanes)]
