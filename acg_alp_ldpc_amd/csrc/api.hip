@@ -133,30 +133,20 @@ struct HostPipe {
     int64_t chunk = 0;       // frames per chunk the buffers are sized for
     size_t y_bytes = 0;      // bytes per frame of the symbol buffers
     void *pin_y[NBUF] = {};
-    uint32_t *pin_bits[NBUF] = {};
-    uint8_t *pin_ok[NBUF] = {};
-    int32_t *pin_it[NBUF] = {};
-    void *dev_y[NBUF] = {};
-    uint32_t *dev_bits[NBUF] = {};
-    uint8_t *dev_ok[NBUF] = {};
-    int32_t *dev_it[NBUF] = {};
+    unsigned char *pin_out[NBUF] = {};  // [frames][nwords] words | [frames] sweep counts | [frames] flags of the chunk in flight:
+    void *dev_y[NBUF] = {};             // one region, so the results come back in ONE device-to-host copy
+    unsigned char *dev_out[NBUF] = {};
     hipStream_t stream[NBUF] = {};
     hipEvent_t done[NBUF] = {};
     HostPool *pool = nullptr;
     void release() {
         for (int b = 0; b < NBUF; b++) {
             if (pin_y[b]) (void) hipHostFree(pin_y[b]);
-            if (pin_bits[b]) (void) hipHostFree(pin_bits[b]);
-            if (pin_ok[b]) (void) hipHostFree(pin_ok[b]);
-            if (pin_it[b]) (void) hipHostFree(pin_it[b]);
+            if (pin_out[b]) (void) hipHostFree(pin_out[b]);
             if (dev_y[b]) (void) hipFree(dev_y[b]);
-            if (dev_bits[b]) (void) hipFree(dev_bits[b]);
-            if (dev_ok[b]) (void) hipFree(dev_ok[b]);
-            if (dev_it[b]) (void) hipFree(dev_it[b]);
+            if (dev_out[b]) (void) hipFree(dev_out[b]);
             pin_y[b] = dev_y[b] = nullptr;
-            pin_bits[b] = dev_bits[b] = nullptr;
-            pin_ok[b] = dev_ok[b] = nullptr;
-            pin_it[b] = dev_it[b] = nullptr;
+            pin_out[b] = dev_out[b] = nullptr;
         }
         chunk = 0;
     }
@@ -929,13 +919,9 @@ static int ensure_pipe(acg_ldpc_decoder *d, int64_t chunk, size_t y_bytes) {
     const int nwords = (d->c.n + 31) / 32;
     for (int b = 0; b < HostPipe::NBUF; b++) {
         HIP_OK(hipHostMalloc(&P.pin_y[b], (size_t) chunk * y_bytes, hipHostMallocDefault));
-        HIP_OK(hipHostMalloc((void **) &P.pin_bits[b], (size_t) chunk * nwords * 4, hipHostMallocDefault));
-        HIP_OK(hipHostMalloc((void **) &P.pin_ok[b], (size_t) chunk, hipHostMallocDefault));
-        HIP_OK(hipHostMalloc((void **) &P.pin_it[b], (size_t) chunk * 4, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void **) &P.pin_out[b], (size_t) chunk * (nwords * 4 + 5), hipHostMallocDefault));
         HIP_OK(hipMalloc(&P.dev_y[b], (size_t) chunk * y_bytes));
-        HIP_OK(hipMalloc((void **) &P.dev_bits[b], (size_t) chunk * nwords * 4));
-        HIP_OK(hipMalloc((void **) &P.dev_ok[b], (size_t) chunk));
-        HIP_OK(hipMalloc((void **) &P.dev_it[b], (size_t) chunk * 4));
+        HIP_OK(hipMalloc((void **) &P.dev_out[b], (size_t) chunk * (nwords * 4 + 5)));
     }
     P.chunk = chunk;
     P.y_bytes = y_bytes;
@@ -1002,13 +988,11 @@ static int decode_batch_host(acg_ldpc_decoder *d, const void *y, int elem, int64
         a.y_is_f64 = (elem == 8) ? 1 : 0;
         a.frames = fc;
         fill_channel(a, snr);
-        a.out_bits = P.dev_bits[b];
-        a.out_ok = P.dev_ok[b];
-        a.out_iters = P.dev_it[b];
+        a.out_bits = reinterpret_cast<uint32_t *>(P.dev_out[b]);
+        a.out_iters = reinterpret_cast<int32_t *>(P.dev_out[b] + (size_t) fc * nwords * 4);
+        a.out_ok = P.dev_out[b] + (size_t) fc * (nwords * 4 + 4);
         if (int rc = launch_decode(d, a, s)) return rc;
-        HIP_OK(hipMemcpyAsync(P.pin_bits[b], P.dev_bits[b], (size_t) fc * nwords * 4, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipMemcpyAsync(P.pin_ok[b], P.dev_ok[b], (size_t) fc, hipMemcpyDeviceToHost, s));
-        if (iters) HIP_OK(hipMemcpyAsync(P.pin_it[b], P.dev_it[b], (size_t) fc * 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(P.pin_out[b], P.dev_out[b], (size_t) fc * (nwords * 4 + 5), hipMemcpyDeviceToHost, s));
         HIP_OK(hipEventRecord(P.done[b], s));
         return 0;
     };
@@ -1016,15 +1000,16 @@ static int decode_batch_host(acg_ldpc_decoder *d, const void *y, int elem, int64
         const int b = (int) (c % HostPipe::NBUF);
         const int64_t fc = chunk_frames(c), f0 = c * chunk;
         HIP_OK(hipEventSynchronize(P.done[b]));
-        std::memcpy(ok + f0, P.pin_ok[b], (size_t) fc);
-        if (iters) std::memcpy(iters + f0, P.pin_it[b], (size_t) fc * 4);
+        const uint32_t *pbits = reinterpret_cast<const uint32_t *>(P.pin_out[b]);
+        std::memcpy(ok + f0, P.pin_out[b] + (size_t) fc * (nwords * 4 + 4), (size_t) fc);
+        if (iters) std::memcpy(iters + f0, P.pin_out[b] + (size_t) fc * nwords * 4, (size_t) fc * 4);
         if (!threads) {
-            unpack_bits(P.pin_bits[b], nwords, n, fc, bits + (size_t) f0 * n);
+            unpack_bits(pbits, nwords, n, fc, bits + (size_t) f0 * n);
             return 0;
         }
         P.pool->run_all([&](int part, int parts) {
             const int64_t lo = fc * part / parts, hi = fc * (part + 1) / parts;
-            unpack_bits(P.pin_bits[b] + (size_t) lo * nwords, nwords, n, hi - lo, bits + (size_t) (f0 + lo) * n);
+            unpack_bits(pbits + (size_t) lo * nwords, nwords, n, hi - lo, bits + (size_t) (f0 + lo) * n);
         });
         return 0;
     };
