@@ -102,6 +102,7 @@ struct AdmmDevTables {
     const int32_t *row_ptr;
     const int32_t *edge_var;
     int32_t n, m, n_var, n_grp, n_gpass, n_vpass, G_pad, V_pad, zero_gslot, nwords;
+    int32_t U_slots;  // workgroup-per-frame kernel: U slots held in LDS (a multiple of 32, <= G_pad): thread slots beyond it are empty
     int32_t lds_bytes_per_frame;
 };
 
@@ -599,7 +600,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
     // LDS: V[V_pad] by variable id (+ zero cell at n_var) | U[G_pad][4] | packed hard decisions
     T *V = reinterpret_cast<T *>(smem);
     const uint32_t u_base = (uint32_t) t.V_pad * (uint32_t) sizeof(T);
-    uint32_t *OB = reinterpret_cast<uint32_t *>(smem + u_base + (size_t) 4 * t.G_pad * sizeof(T));
+    uint32_t *OB = reinterpret_cast<uint32_t *>(smem + u_base + (size_t) 4 * t.U_slots * sizeof(T));
     // ---- loop-invariant per-thread structure -> registers ------------------------------------------------------------
     uint32_t mem[BP][3];  // member k of my group in pass p: LDS byte address of V[member] | address of U[group][wpos k] << 16
     uint32_t tys = 0;          // group type of pass p at bits 2p..2p+1 (0 = padding slot)
@@ -668,7 +669,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
         for (int p = 0; p < BP; ++p) {
 #pragma unroll
             for (int row = 0; row < 4; ++row) ylreg[p][row] = (T) 0;  // z = yl = 0 (qp_admm.h:120-121)
-            if (p < t.n_gpass) {
+            if (p < t.n_gpass && p * L + l < t.U_slots) {  // (thread slots beyond the U array hold no group)
                 T *pu = reinterpret_cast<T *>(smem + u3_0 + (uint32_t) p * u3_step) - 96;  // U[slot][row] = pu[32 * row]
                 pu[0] = pu[32] = pu[64] = (T) 0 + mu * ((T) 0 - (T) 0);
                 pu[96] = (((tys >> (2 * p)) & 3u) == 3u) ? (T) 0 + mu * ((T) 0 - (T) 2) : (T) 0 + mu * ((T) 0 - (T) 0);
@@ -912,6 +913,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
     t.nwords = (c.n + 31) / 32;
     t.n_gpass = (A.n_grp + 1 + L - 1) / L;  // +1: at least one padding slot that stays all-zero
     t.G_pad = t.n_gpass * L;
+    t.U_slots = t.G_pad;
     t.zero_gslot = A.n_grp;
     if (t.G_pad >= (1 << 20) || A.n_var >= (1 << 24)) {
         err = "code too large for the fused QP-ADMM kernel";
@@ -952,6 +954,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         for (size_t sidx = 0; sidx < var_of_slot.size(); sidx++) var_of_slot[sidx] = P.var_of_slot[sidx];
         t.zero_gslot = P.zero_gslot;
         t.V_pad = (P.n_cells + 3) & ~3;
+        t.U_slots = P.u_slots;
     } else {
         std::vector<int> vorder(A.n_var);
         for (int i = 0; i < A.n_var; i++) vorder[i] = i;
@@ -991,7 +994,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         auto u_addr = [&](int gs, int row) {
             return u_base + (((uint32_t) gs >> 5) * 128u + (uint32_t) row * 32u + ((uint32_t) gs & 31u)) * ts;
         };
-        if (u_addr(t.G_pad, 0) + (uint32_t) t.nwords * 4 > 0xFFFFu) {
+        if (u_addr(t.U_slots, 0) + (uint32_t) t.nwords * 4 > 0xFFFFu) {
             err = "QP-ADMM frame state exceeds the 64 KiB the workgroup-per-frame kernel addresses";
             admm_device_destroy(d);
             return nullptr;
@@ -1083,7 +1086,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         return nullptr;
     }
     const size_t ts = d->f32 ? 4 : 8;
-    size_t per_frame = (size_t) (4 * t.G_pad + t.V_pad + (d->blockmode ? 0 : t.n_vpass * L)) * ts + (size_t) t.nwords * 4;
+    size_t per_frame = (size_t) (4 * (d->blockmode ? t.U_slots : t.G_pad) + t.V_pad + (d->blockmode ? 0 : t.n_vpass * L)) * ts + (size_t) t.nwords * 4;
     per_frame = (per_frame + 15) & ~(size_t) 15;
     t.lds_bytes_per_frame = (int) per_frame;
     if (d->blockmode) {

@@ -652,7 +652,7 @@ void admm_assign_pads(const Code &c, AdmmBlockPlacement &P, bool spread) {
     if (spread) {
         std::vector<char> used((size_t) P.n_gpass * L, 0);
         for (int g = 0; g < A.n_grp; g++) used[P.slot_of_grp[g]] = 1;
-        for (int sl = 0; sl < P.n_gpass * L; sl++)
+        for (int sl = 0; sl < P.u_slots; sl++)
             if (!used[sl]) free_of_bank[sl % 32].push_back(sl);
     }
     for (int p = 0; p < P.n_vpass; p++)
@@ -703,6 +703,7 @@ void admm_placement_annealed(const Code &c, AdmmBlockPlacement &P, bool f32, boo
         }
     }
     P.zero_gslot = A.n_grp;
+    P.u_slots = P.n_gpass * L;
     P.zero_cell = A.n_var;
     P.n_cells = A.n_var + 1;
     P.cell_of_var.resize(A.n_var);
@@ -1003,19 +1004,13 @@ bool admm_placement_qc(const Code &c, AdmmBlockPlacement &P) {
             load[best] += S[0].label[order[u0]];
             for (int x = u0; x < std::min(n_vt, u0 + unit); x++) S[0].pos[order[x]] = pass * per_pass + best * unit + (x - u0);
         }
-        // group tuples: pass-major, the last (partial) pass goes to the wavefronts with the lightest v-update load
-        std::vector<int> worder(waves);
-        std::iota(worder.begin(), worder.end(), 0);
-        std::stable_sort(worder.begin(), worder.end(), [&](int x, int y) { return load[x] < load[y]; });
+        // group tuples: pass-major.  The last (partial) pass fills the first wavefronts, so that the U array the kernel
+        // keeps in LDS can end right behind it (576 instead of 768 slots for H05: a sixth workgroup per CU fits)
         S[1].pos.assign(n_gt, -1);
         int x = 0;
-        for (int pass = 0; pass < P.n_gpass && x < n_gt; pass++) {
-            const bool last = (n_gt - x) < per_pass;
-            for (int wi = 0; wi < waves && x < n_gt; wi++) {
-                const int w = last ? worder[wi] : wi;
+        for (int pass = 0; pass < P.n_gpass && x < n_gt; pass++)
+            for (int w = 0; w < waves && x < n_gt; w++)
                 for (int o = 0; o < unit && x < n_gt; o++, x++) S[1].pos[x] = pass * per_pass + w * unit + o;
-            }
-        }
     }
     // group tuples carry no label constraint except "stay in the same pass occupancy": label = pass so the row phase
     // keeps its per-wavefront pass counts; variable tuples: label = list length
@@ -1041,10 +1036,20 @@ bool admm_placement_qc(const Code &c, AdmmBlockPlacement &P) {
         used[slot] = 1;
         P.slot_of_grp[gi] = slot;
     }
+    // U slots the kernel has to hold: everything up to the end of the last wavefront-pass unit that holds a group, which
+    // must also offer free (all-zero) slots for the list padding
+    int top = 0;
+    for (int sl = 0; sl < P.n_gpass * L; sl++)
+        if (used[sl]) top = sl;
+    P.u_slots = std::min(P.n_gpass * L, (top / 64 + 1) * 64);
     P.zero_gslot = -1;
-    for (int sl = P.n_gpass * L - 1; sl >= 0 && P.zero_gslot < 0; sl--)
+    for (int sl = P.u_slots - 1; sl >= 0 && P.zero_gslot < 0; sl--)
         if (!used[sl]) P.zero_gslot = sl;
-    if (P.zero_gslot < 0) return false;
+    if (P.zero_gslot < 0) {  // the last unit is full: one more tile
+        if (P.u_slots + 32 > P.n_gpass * L) return false;
+        P.zero_gslot = P.u_slots;
+        P.u_slots += 32;
+    }
     P.zero_cell = P.n_vpass * L;
     P.n_cells = P.n_vpass * L + 1;
     P.n3 = 0;

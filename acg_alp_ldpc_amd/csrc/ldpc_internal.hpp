@@ -120,6 +120,7 @@ struct AdmmBlockPlacement {
     int n_cells = 0;      // V cells incl. the zero cell
     int zero_cell = 0;    // a cell that is always 0.0 (absent members of one- / two-variable checks)
     int zero_gslot = 0;   // a U slot that is always all-zero (list padding)
+    int u_slots = 0;      // U slots the kernel must hold: every occupied / zero / padding slot is below it (multiple of 32)
     std::vector<int> var_of_slot;  // [n_vpass*L] variable id or -1
     std::vector<int> slot_of_grp;  // [n_grp]
     std::vector<int> cell_of_var;  // [n_var]
