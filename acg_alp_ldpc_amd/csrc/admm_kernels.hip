@@ -102,6 +102,7 @@ struct AdmmDevTables {
     const int32_t *row_ptr;
     const int32_t *edge_var;
     int32_t n, m, n_var, n_grp, n_gpass, n_vpass, G_pad, V_pad, zero_gslot, nwords;
+    int32_t cell_is_slot;  // workgroup-per-frame kernel: 1 = the V cell of every variable is its thread slot (quasi-cyclic placement): no address table in registers
     int32_t U_slots;  // workgroup-per-frame kernel: U slots held in LDS (a multiple of 32, <= G_pad): thread slots beyond it are empty
     int32_t lds_bytes_per_frame;
 };
@@ -470,6 +471,9 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
 constexpr int ADMM_BLK = 256;
 constexpr int ADMM_BP = 4;  // most passes any instance handles
 constexpr int ADMM_VK = 6;  // list entries per variable slot kept in registers (longer lists continue from global)
+// ... of pass p: the host deals the variables out longest list first, so later passes hold the short lists (H05: 6/5/4/4,
+// then 3/2/2/2, then 2/2/2/-) and need fewer registers; whatever is longer continues from global memory as well
+__host__ __device__ constexpr int admm_vk(int p) { return p == 0 ? ADMM_VK : p == 1 ? 4 : 2; }
 #ifndef ADMM_OCC
 #define ADMM_OCC 8  // launch bound: ADMM_OCC - BP workgroups of 4 wavefronts per CU
 #endif
@@ -485,12 +489,14 @@ template <> struct AdmmVec<double> {
     }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
+    static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
 };
 template <> struct AdmmVec<float> {
     typedef float v4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ float pm1(uint32_t x) { return __uint_as_float((x & 0x80000000u) | 0x3F800000u); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
+    static __device__ __forceinline__ float min(float a, float b) { return __builtin_fminf(a, b); }
 };
 
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v, const int ctrl_tag) {
@@ -543,6 +549,66 @@ __device__ __forceinline__ void admm_read_rows(unsigned char *smem, const uint32
     w = pu[96];
 }
 
+// The first ADMM_VK entries of a variable's list as ONE asm statement: a two-deep pipeline of the row reads (the four
+// ds_read of entry k+1 are in flight while the four fma/add of entry k run; LDS operations complete in order, so
+// `s_waitcnt lgkmcnt(4)` after issuing entry k+1 means entry k has arrived).  It has to be a single statement: a value the
+// LDS has not delivered yet must never be visible to the compiler, which is free to copy it (measured: it does).  The
+// buffers are fixed registers v40..v59 named as clobbers, because a 64-bit operand cannot name its high half, which
+// the +-1 multiplier is built in ((flag & 0x80000000) | high word of 1.0).  Same operations in the same order as
+// admm_read_rows + fma: B = fma(+-1, u0, B); fma(+-1, u1, B); fma(+-1, u2, B); B + u3 per entry.
+#ifndef ADMM_PREFETCH
+#define ADMM_PREFETCH 1
+#endif
+#define ACH_ISSUE(RD, O1, O2, O3, X0, X1, X2, X3, E)                                                                       \
+    "v_add_u32_sdwa v59, %[base], " E " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" RD " " X0   \
+    ", v59\n\t" RD " " X1 ", v59 offset:" O1 "\n\t" RD " " X2 ", v59 offset:" O2 "\n\t" RD " " X3 ", v59 offset:" O3 "\n\t"
+#define ACH_ACC(FMA, ADD, PMH, PM, X0, X1, X2, X3, E)                                                                      \
+    "v_and_or_b32 " PMH ", " E ", %[k80], %[one]\n\t" FMA " %[B], " PM ", " X0 ", %[B]\n\t"                                  \
+    "v_lshlrev_b32 v58, 1, " E "\n\tv_and_or_b32 " PMH ", v58, %[k80], %[one]\n\t" FMA " %[B], " PM ", " X1 ", %[B]\n\t"     \
+    "v_lshlrev_b32 v58, 2, " E "\n\tv_and_or_b32 " PMH ", v58, %[k80], %[one]\n\t" FMA " %[B], " PM ", " X2 ", %[B]\n\t" ADD \
+    " %[B], " X3 ", %[B]\n\t"
+#define ACH_BODY(ISS_A, ISS_B, ACC_A, ACC_B)                                                                               \
+    ISS_A("%[e0]") "s_cmp_lt_u32 %[ml], 2\n\ts_cbranch_scc1 .Lach0_%=\n\t"                                                 \
+    ISS_B("%[e1]") "s_waitcnt lgkmcnt(4)\n\t" ACC_A("%[e0]") "s_cmp_lt_u32 %[ml], 3\n\ts_cbranch_scc1 .Lach1_%=\n\t"      \
+    ISS_A("%[e2]") "s_waitcnt lgkmcnt(4)\n\t" ACC_B("%[e1]") "s_cmp_lt_u32 %[ml], 4\n\ts_cbranch_scc1 .Lach2_%=\n\t"      \
+    ISS_B("%[e3]") "s_waitcnt lgkmcnt(4)\n\t" ACC_A("%[e2]") "s_cmp_lt_u32 %[ml], 5\n\ts_cbranch_scc1 .Lach3_%=\n\t"      \
+    ISS_A("%[e4]") "s_waitcnt lgkmcnt(4)\n\t" ACC_B("%[e3]") "s_cmp_lt_u32 %[ml], 6\n\ts_cbranch_scc1 .Lach4_%=\n\t"      \
+    ISS_B("%[e5]") "s_waitcnt lgkmcnt(4)\n\t" ACC_A("%[e4]")                                                              \
+    "s_waitcnt lgkmcnt(0)\n\t" ACC_B("%[e5]") "s_branch .Lachend_%=\n"                                                     \
+    ".Lach0_%=:\n\ts_waitcnt lgkmcnt(0)\n\t" ACC_A("%[e0]") "s_branch .Lachend_%=\n"                                        \
+    ".Lach1_%=:\n\ts_waitcnt lgkmcnt(0)\n\t" ACC_B("%[e1]") "s_branch .Lachend_%=\n"                                        \
+    ".Lach2_%=:\n\ts_waitcnt lgkmcnt(0)\n\t" ACC_A("%[e2]") "s_branch .Lachend_%=\n"                                        \
+    ".Lach3_%=:\n\ts_waitcnt lgkmcnt(0)\n\t" ACC_B("%[e3]") "s_branch .Lachend_%=\n"                                        \
+    ".Lach4_%=:\n\ts_waitcnt lgkmcnt(0)\n\t" ACC_A("%[e4]") ".Lachend_%=:"
+#define ACH64_ISS_A(E) ACH_ISSUE("ds_read_b64", "256", "512", "768", "v[40:41]", "v[42:43]", "v[44:45]", "v[46:47]", E)
+#define ACH64_ISS_B(E) ACH_ISSUE("ds_read_b64", "256", "512", "768", "v[48:49]", "v[50:51]", "v[52:53]", "v[54:55]", E)
+#define ACH64_ACC_A(E) ACH_ACC("v_fma_f64", "v_add_f64", "v57", "v[56:57]", "v[40:41]", "v[42:43]", "v[44:45]", "v[46:47]", E)
+#define ACH64_ACC_B(E) ACH_ACC("v_fma_f64", "v_add_f64", "v57", "v[56:57]", "v[48:49]", "v[50:51]", "v[52:53]", "v[54:55]", E)
+#define ACH32_ISS_A(E) ACH_ISSUE("ds_read_b32", "128", "256", "384", "v40", "v41", "v42", "v43", E)
+#define ACH32_ISS_B(E) ACH_ISSUE("ds_read_b32", "128", "256", "384", "v44", "v45", "v46", "v47", E)
+#define ACH32_ACC_A(E) ACH_ACC("v_fma_f32", "v_add_f32", "v56", "v56", "v40", "v41", "v42", "v43", E)
+#define ACH32_ACC_B(E) ACH_ACC("v_fma_f32", "v_add_f32", "v56", "v56", "v44", "v45", "v46", "v47", E)
+static_assert(ADMM_VK == 6, "the asm chain below is written for six register-resident entries");
+__device__ __forceinline__ void admm_v_chain(unsigned char *smem, const uint32_t (&e)[ADMM_VK], const uint32_t ml, const uint32_t lds0, const uint32_t k80,
+                                             const uint32_t one_hi, double &B) {
+    const uint32_t base = lds0 + (uint32_t) (uintptr_t) smem;
+    asm volatile("v_mov_b32 v56, 0\n\t" ACH_BODY(ACH64_ISS_A, ACH64_ISS_B, ACH64_ACC_A, ACH64_ACC_B)
+                 : [B] "+v"(B)
+                 : [base] "s"(base), [ml] "s"(ml), [k80] "s"(k80), [one] "v"(one_hi), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]),
+                   [e4] "v"(e[4]), [e5] "v"(e[5])
+                 : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58",
+                   "v59", "scc", "memory");
+}
+__device__ __forceinline__ void admm_v_chain(unsigned char *smem, const uint32_t (&e)[ADMM_VK], const uint32_t ml, const uint32_t lds0, const uint32_t k80,
+                                             const uint32_t one_hi, float &B) {
+    const uint32_t base = lds0 + (uint32_t) (uintptr_t) smem;
+    asm volatile(ACH_BODY(ACH32_ISS_A, ACH32_ISS_B, ACH32_ACC_A, ACH32_ACC_B)
+                 : [B] "+v"(B)
+                 : [base] "s"(base), [ml] "s"(ml), [k80] "s"(k80), [one] "v"(one_hi), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]),
+                   [e4] "v"(e[4]), [e5] "v"(e[5])
+                 : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v56", "v58", "v59", "scc", "memory");
+}
+
 // One constraint group (slot order, see above).  GENERIC also handles one- and two-variable checks, whose missing
 // slots must stay all-zero; the host puts those groups into passes/wavefronts flagged for the GENERIC instance so the
 // common instance carries no selects.  State yl[] = max(0, yl - r) of the previous sweep (qp_admm.h:157).
@@ -571,7 +637,10 @@ __device__ __forceinline__ void admm_group_update(unsigned char *smem, const uin
         const T wn = r[s] - yl[s];
         const T z = X::max(wn, (T) 0);
         yl[s] = X::max(-wn, (T) 0);
-        if (s < 3) u[s] = X::max(mu * z, -wn);  // yl + mu*(z - 0): one of yl, z is zero and x + 0 is exact
+        // rows 0..2: yl + mu*(z - 0), and one of yl, z is zero (x + 0 is exact), so it is max(mu*z, -wn); without the
+        // stopping rule z itself is not needed: mu*max(wn, 0) == max(mu*wn, 0) for mu > 0 (the same product, or zero),
+        // and one of mu*wn, -wn is >= 0, so the value is max(mu*wn, -wn) — one operation less
+        if (s < 3) u[s] = EE ? X::max(mu * z, -wn) : X::max(mu * wn, -wn);
         else u[s] = yl[s] + mu * (z - (T) 2);
         if (EE) {
             const T dd = z - r[s];
@@ -617,25 +686,27 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
     uint32_t ent[BP][ADMM_VK];  // list entries: LDS byte address of U[group][0] | "coefficient is -1" flags, row r at bit 31-r
     uint32_t mlw_pk = 0;             // list length of (pass p, my wavefront) at bits 8p..8p+7
     uint32_t gen_pk = 0;             // bit p: (pass p, my wavefront) holds one- or two-variable checks
-    int vaddr[BP];              // LDS byte address of my variable in pass p, -1 = none
+    // LDS byte address of my variable in pass p: its thread slot when the placement says so (cell_is_slot), otherwise read
+    // from the table once per sweep (ahead of the list, so the list hides the load); bit 8+p of tys = "I own a variable"
+    const bool cell_slot = t.cell_is_slot != 0;
     T inv[BP];
     const T *inv_coef = reinterpret_cast<const T *>(t.inv_coef);
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
-        vaddr[p] = -1;
         inv[p] = (T) 0;
 #pragma unroll
-        for (int k = 0; k < ADMM_VK; ++k) ent[p][k] = 0;
+        for (int k = 0; k < ADMM_VK; ++k)
+            if (k < admm_vk(p)) ent[p][k] = 0;
         if (p < t.n_gpass) gen_pk |= (uint32_t) (t.blk_generic[p * 4 + wave] != 0) << p;
         if (p < t.n_vpass) {
             const int ml = t.blk_mlw[p * 4 + wave];
             mlw_pk |= (uint32_t) ml << (8 * p);
             const int cell = t.blk_cell[p * L + l];
-            vaddr[p] = (cell >= 0) ? cell * (int) sizeof(T) : -1;
+            tys |= (cell >= 0 ? 1u : 0u) << (8 + p);
             inv[p] = inv_coef[p * L + l];
 #pragma unroll
             for (int k = 0; k < ADMM_VK; ++k)
-                if (k < ml) ent[p][k] = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
+                if (k < admm_vk(p) && k < ml) ent[p][k] = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
         }
     }
     mlw_pk = (uint32_t) __builtin_amdgcn_readfirstlane((int) mlw_pk);
@@ -652,6 +723,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
         const int64_t frame = (int64_t) fr_lds;
         if (frame >= a.frames) break;
         // ---- start of a frame --------------------------------------------------------------------------------
+        bool q_nan = false;
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
             T q = (T) 0;  // auxiliaries: q = 0 (qp_admm.h:24)
@@ -662,8 +734,12 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                     else q = (T) (2 * (double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + i] / a.var);
                 }
             }
-            qreg[p] = q;  // CalculateCoef, algo/algo.h:13-20
+            qreg[p] = q + (alpha / 2);  // CalculateCoef, algo/algo.h:13-20; the v-update starts from q_i + alpha/2 (qp_admm.h:133)
+            q_nan |= (q != q);
         }
+        // A NaN symbol is the only way a NaN gets into a frame (v is clamped to [0, 1], so nothing overflows): such frames
+        // take the comparison form of the clamp below, which hands a NaN on exactly as std::max/std::min do.
+        const bool nan_frame = __syncthreads_or(q_nan) != 0;
         for (int w = l; w < t.V_pad; w += L) V[w] = (T) 0;
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
@@ -687,6 +763,8 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
             if (sizeof(T) == 8) asm volatile("v_mov_b32 %0, 0x3ff00000" : "=v"(one_hi));  // in a VGPR: (x & k80) | one_hi is one v_and_or_b32
             else asm volatile("v_mov_b32 %0, 1.0" : "=v"(one_hi));
             asm volatile("" : "+s"(mlw_o), "+s"(gen_o));
+            uint32_t l_o = (uint32_t) l;  // (opaque too: one shift-add per pass instead of a hoisted, then spilled, address)
+            asm volatile("" : "+v"(l_o));
             auto pm1 = [&](uint32_t x) -> T {  // bit 31 of x set -> -1, else +1
                 const uint32_t hi = (x & k80) | one_hi;
                 if constexpr (sizeof(T) == 8) return (T) __hiloint2double((int) hi, 0);
@@ -696,10 +774,19 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
             for (int p = 0; p < BP; ++p) {
                 const int ml = (int) ((mlw_o >> (8 * p)) & 0xFFu);
                 if (p < t.n_vpass && ml > 0) {  // v-update (qp_admm.h:132-142); ml == 0: no variable of my wavefront here
-                    T B = qreg[p] + (alpha / 2);
+                    T B = qreg[p];
+                    const uint32_t v_cell = cell_slot ? 0u : (uint32_t) t.blk_cell[(uint32_t) (p * L) + l_o];
+#if ADMM_PREFETCH
+                    {  // (entries past admm_vk(p) are never touched: the chain runs min(ml, admm_vk(p)) entries)
+                        uint32_t ec[ADMM_VK];
+#pragma unroll
+                        for (int k = 0; k < ADMM_VK; ++k) ec[k] = ent[p][k < admm_vk(p) ? k : 0];
+                        admm_v_chain(smem, ec, (uint32_t) (ml < admm_vk(p) ? ml : admm_vk(p)), lds0, k80, one_hi, B);
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < ADMM_VK; ++k)
-                        if (k < ml) {
+                        if (k < admm_vk(p) && k < ml) {
                             const uint32_t e = ent[p][k];
                             T ux, uy, uz, uw;
                             admm_read_rows(smem, (e & 0xFFFFu) + lds0, ux, uy, uz, uw);
@@ -709,7 +796,8 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                             B = B + uw;  // row 3 (x_i + x_j + x_h <= 2, qp_admm.h:52-57) has coefficient +1 for every member;
                                          // one- and two-variable checks have no such row and keep u = 0 there
                         }
-                    for (int k = ADMM_VK; k < ml; ++k) {  // lists longer than the register file holds
+#endif
+                    for (int k = admm_vk(p); k < ml; ++k) {  // lists longer than the register file holds
                         const uint32_t e = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
                         T ux, uy, uz, uw;
                         admm_read_rows(smem, (e & 0xFFFFu) + lds0, ux, uy, uz, uw);
@@ -718,10 +806,20 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                         B = X::fma(pm1(e << k2), uz, B);
                         B = B + uw;
                     }
+                    // std::min(std::max(v, 0.0), 1.0) (qp_admm.h:140-141) as two instructions; they can differ from the
+                    // comparisons only in the sign of a zero, which no later value, comparison or decision depends on
+                    // (NaN aside: max/min drop a NaN, the comparisons keep it — frames with a NaN symbol go the long way)
                     T v = B * inv[p];
-                    v = (v < (T) 0) ? (T) 0 : v;  // std::max(v, 0.0)
-                    v = ((T) 1 < v) ? (T) 1 : v;  // std::min(v, 1.0)
-                    if (vaddr[p] >= 0) *reinterpret_cast<T *>(smem + vaddr[p]) = v;
+                    if (nan_frame) {  // workgroup-uniform
+                        v = (v < (T) 0) ? (T) 0 : v;  // std::max(v, 0.0)
+                        v = ((T) 1 < v) ? (T) 1 : v;  // std::min(v, 1.0)
+                    } else {
+                        v = X::min(X::max(v, (T) 0), (T) 1);
+                    }
+                    if ((tys >> (8 + p)) & 1u) {
+                        const uint32_t va = cell_slot ? l_o * (uint32_t) sizeof(T) + (lds0 + (uint32_t) (p * L) * (uint32_t) sizeof(T)) : v_cell * (uint32_t) sizeof(T);
+                        *reinterpret_cast<T *>(smem + va) = v;
+                    }
                 }
             }
             __syncthreads();
@@ -758,7 +856,10 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
         for (int p = 0; p < BP; ++p)
             if (p < t.n_vpass) {  // every thread reports the variables it owns (V is indexed by cell, not by variable id)
                 const int i = t.var_of_slot[p * L + l];
-                if (i >= 0 && i < t.n && !(*reinterpret_cast<const T *>(smem + vaddr[p]) <= (T) 0.5)) atomicOr(&OB[i >> 5], 1u << (i & 31));
+                if (i >= 0 && i < t.n) {
+                    const uint32_t va = (cell_slot ? (uint32_t) (p * L + l) : (uint32_t) t.blk_cell[p * L + l]) * (uint32_t) sizeof(T);
+                    if (!(*reinterpret_cast<const T *>(smem + va) <= (T) 0.5)) atomicOr(&OB[i >> 5], 1u << (i & 31));
+                }
             }
         __syncthreads();
         if (a.out_bits)
@@ -1064,6 +1165,9 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         t.grp_type_slot = (const uint8_t *) upload_vec(type_slot, d->allocs, err);
         t.blk_generic = (const uint8_t *) upload_vec(blk_generic, d->allocs, err);
         t.blk_cell = (const int32_t *) upload_vec(blk_cell, d->allocs, err);
+        t.cell_is_slot = 1;
+        for (int sidx = 0; sidx < t.n_vpass * L; sidx++)
+            if (blk_cell[sidx] >= 0 && blk_cell[sidx] != sidx) t.cell_is_slot = 0;
         ok = t.blk_mem && t.blk_list && t.blk_mlw && t.grp_type_slot && t.blk_generic && t.blk_cell;
     }
     t.grp_mem = (const uint32_t *) upload_vec(grp_mem, d->allocs, err);
