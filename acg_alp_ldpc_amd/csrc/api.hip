@@ -534,7 +534,10 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     if (lay.a_words < ((c.n + 3) & ~3)) lay.a_words = (c.n + 3) & ~3;
     const size_t ts = d->f64 ? 8 : 4;
     // channel LLRs: in registers when there are at most 12 variable passes (degree <= 8 kernels), else in LDS
-    const bool llr_regs = blockmode || ((d->maxd <= 8) && (lay.n_vpass <= 12));
+    // the fused kernels keep their LDS copy of the variable-side index table in BYTE offsets (16 bits): the message
+    // array of a frame has to stay below 64 KiB for that copy (and the register-LLR instances, which require it)
+    const bool a_fits16 = blockmode || (size_t) lay.a_words * ts <= 65535;
+    const bool llr_regs = blockmode || ((d->maxd <= 8) && (lay.n_vpass <= 12) && a_fits16);
     const int llr_words = llr_regs ? 0 : lay.n_vpass * L;
     size_t per_frame = (size_t) (lay.a_words + llr_words) * ts + (size_t) nwords * 4;
     if (pair) per_frame = (size_t) lay.a_words * 4 + 2 * (size_t) nwords * 4;  // one 32-bit word per edge for TWO frames
@@ -571,7 +574,7 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     t.v_apos_len = lay.v_apos_len;
     // the variable-side index table is read by every wave in every iteration: keep a block-shared
     // copy in LDS unless it is large (then it is read through L1/L2)
-    bool idxlds = (size_t) lay.v_apos_len * 2 <= 16 * 1024 || (llr_regs && !blockmode);
+    bool idxlds = a_fits16 && ((size_t) lay.v_apos_len * 2 <= 16 * 1024 || (llr_regs && !blockmode));
     if (blockmode) idxlds = (size_t) lay.v_apos_len * 2 <= 32 * 1024 &&
                             (((size_t) lay.v_apos_len * 2 + 15) & ~(size_t) 15) + per_frame <= 158 * 1024;
     t.idx_lds_bytes = idxlds ? (int) (((size_t) lay.v_apos_len * 2 + 15) & ~(size_t) 15) : 0;
