@@ -555,18 +555,22 @@ __device__ __forceinline__ void admm_read_rows(unsigned char *smem, const uint32
 // LDS has not delivered yet must never be visible to the compiler, which is free to copy it (measured: it does).  The
 // buffers are fixed registers v40..v59 named as clobbers, because a 64-bit operand cannot name its high half, which
 // the +-1 multiplier is built in ((flag & 0x80000000) | high word of 1.0).  Same operations in the same order as
-// admm_read_rows + fma: B = fma(+-1, u0, B); fma(+-1, u1, B); fma(+-1, u2, B); B + u3 per entry.
-#ifndef ADMM_PREFETCH
-#define ADMM_PREFETCH 1
-#endif
+// admm_read_rows + fma: B = fma(+-1, u0, B); fma(+-1, u1, B); fma(+-1, u2, B); B + u3 per entry.  The entries carry
+// ABSOLUTE LDS addresses in their low halves (the kernel adds the start of its dynamic LDS when it loads them): one
+// v_and_b32 per entry, no SDWA add (half rate).
 #define ACH_ISSUE(RD, O1, O2, O3, X0, X1, X2, X3, E)                                                                       \
-    "v_add_u32_sdwa v59, %[base], " E " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" RD " " X0   \
-    ", v59\n\t" RD " " X1 ", v59 offset:" O1 "\n\t" RD " " X2 ", v59 offset:" O2 "\n\t" RD " " X3 ", v59 offset:" O3 "\n\t"
+    "v_and_b32 v59, 0xffff, " E "\n\t" RD " " X0 ", v59\n\t" RD " " X1 ", v59 offset:" O1 "\n\t" RD " " X2 ", v59 offset:" O2 \
+    "\n\t" RD " " X3 ", v59 offset:" O3 "\n\t"
+// The +-1 multipliers of rows 0..2 (flag "coefficient is -1" of row r at bit 31-r of the entry): row 0 by and-or; row 1
+// from e + e (v_add_u32 issues at twice the rate of v_lshlrev_b32, profiles/r02_valu_op_rates.txt); row 2 by
+// exclusive-or of the first two sign bits — exactly one of the three rows has coefficient +1 (the row in which the member
+// sits, qp_admm.h:48-70), so s2 = s0 ^ s1; for the one- and two-variable checks the rows beyond hold u = 0 and the sign
+// does not matter.  17 issue cycles of integer work per entry instead of 21.
 #define ACH_ACC(FMA, ADD, PMH, PM, X0, X1, X2, X3, E)                                                                      \
     "v_and_or_b32 " PMH ", " E ", %[k80], %[one]\n\t" FMA " %[B], " PM ", " X0 ", %[B]\n\t"                                  \
-    "v_lshlrev_b32 v58, 1, " E "\n\tv_and_or_b32 " PMH ", v58, %[k80], %[one]\n\t" FMA " %[B], " PM ", " X1 ", %[B]\n\t"     \
-    "v_lshlrev_b32 v58, 2, " E "\n\tv_and_or_b32 " PMH ", v58, %[k80], %[one]\n\t" FMA " %[B], " PM ", " X2 ", %[B]\n\t" ADD \
-    " %[B], " X3 ", %[B]\n\t"
+    "v_add_u32 v58, " E ", " E "\n\tv_and_b32 v59, %[k80], " PMH "\n\tv_and_or_b32 " PMH ", v58, %[k80], %[one]\n\t" FMA        \
+    " %[B], " PM ", " X1 ", %[B]\n\t"                                                                                        \
+    "v_xor_b32 " PMH ", v59, " PMH "\n\t" FMA " %[B], " PM ", " X2 ", %[B]\n\t" ADD " %[B], " X3 ", %[B]\n\t"
 #define ACH_BODY(ISS_A, ISS_B, ACC_A, ACC_B)                                                                               \
     ISS_A("%[e0]") "s_cmp_lt_u32 %[ml], 2\n\ts_cbranch_scc1 .Lach0_%=\n\t"                                                 \
     ISS_B("%[e1]") "s_waitcnt lgkmcnt(4)\n\t" ACC_A("%[e0]") "s_cmp_lt_u32 %[ml], 3\n\ts_cbranch_scc1 .Lach1_%=\n\t"      \
@@ -589,22 +593,18 @@ __device__ __forceinline__ void admm_read_rows(unsigned char *smem, const uint32
 #define ACH32_ACC_A(E) ACH_ACC("v_fma_f32", "v_add_f32", "v56", "v56", "v40", "v41", "v42", "v43", E)
 #define ACH32_ACC_B(E) ACH_ACC("v_fma_f32", "v_add_f32", "v56", "v56", "v44", "v45", "v46", "v47", E)
 static_assert(ADMM_VK == 6, "the asm chain below is written for six register-resident entries");
-__device__ __forceinline__ void admm_v_chain(unsigned char *smem, const uint32_t (&e)[ADMM_VK], const uint32_t ml, const uint32_t lds0, const uint32_t k80,
-                                             const uint32_t one_hi, double &B) {
-    const uint32_t base = lds0 + (uint32_t) (uintptr_t) smem;
+__device__ __forceinline__ void admm_v_chain(const uint32_t (&e)[ADMM_VK], const uint32_t ml, const uint32_t k80, const uint32_t one_hi, double &B) {
     asm volatile("v_mov_b32 v56, 0\n\t" ACH_BODY(ACH64_ISS_A, ACH64_ISS_B, ACH64_ACC_A, ACH64_ACC_B)
                  : [B] "+v"(B)
-                 : [base] "s"(base), [ml] "s"(ml), [k80] "s"(k80), [one] "v"(one_hi), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]),
+                 : [ml] "s"(ml), [k80] "s"(k80), [one] "v"(one_hi), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]),
                    [e4] "v"(e[4]), [e5] "v"(e[5])
                  : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58",
                    "v59", "scc", "memory");
 }
-__device__ __forceinline__ void admm_v_chain(unsigned char *smem, const uint32_t (&e)[ADMM_VK], const uint32_t ml, const uint32_t lds0, const uint32_t k80,
-                                             const uint32_t one_hi, float &B) {
-    const uint32_t base = lds0 + (uint32_t) (uintptr_t) smem;
+__device__ __forceinline__ void admm_v_chain(const uint32_t (&e)[ADMM_VK], const uint32_t ml, const uint32_t k80, const uint32_t one_hi, float &B) {
     asm volatile(ACH_BODY(ACH32_ISS_A, ACH32_ISS_B, ACH32_ACC_A, ACH32_ACC_B)
                  : [B] "+v"(B)
-                 : [base] "s"(base), [ml] "s"(ml), [k80] "s"(k80), [one] "v"(one_hi), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]),
+                 : [ml] "s"(ml), [k80] "s"(k80), [one] "v"(one_hi), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]),
                    [e4] "v"(e[4]), [e5] "v"(e[5])
                  : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v56", "v58", "v59", "scc", "memory");
 }
@@ -617,9 +617,11 @@ __device__ __forceinline__ void admm_group_update(unsigned char *smem, const uin
                                                   const uint32_t m2, const uint32_t u3_addr, const uint32_t ty, const T mu,
                                                   T (&yl)[4], T &sum2) {
     using X = AdmmVec<T>;
-    const T v0 = *reinterpret_cast<const T *>(smem + ((m0 & 0xFFFFu) + lds0));
-    const T v1 = *reinterpret_cast<const T *>(smem + ((m1 & 0xFFFFu) + lds0));
-    const T v2 = *reinterpret_cast<const T *>(smem + ((m2 & 0xFFFFu) + lds0));
+    // (m0..m2 are opaque copies made inside the sweep loop, so these stay one v_and_b32 / v_lshrrev_b32 each — full-rate
+    // operations, unlike the SDWA add they replace — instead of being hoisted into seven address registers per pass)
+    const T v0 = *reinterpret_cast<const T *>(smem + (m0 & 0xFFFFu));
+    const T v1 = *reinterpret_cast<const T *>(smem + (m1 & 0xFFFFu));
+    const T v2 = *reinterpret_cast<const T *>(smem + (m2 & 0xFFFFu));
     const T d01 = v0 - v1;
     T r[4];
     r[0] = v2 - d01;        // ((0 - v0) + v1) + v2
@@ -648,9 +650,9 @@ __device__ __forceinline__ void admm_group_update(unsigned char *smem, const uin
         }
     }
     if (GENERIC && ty != 3u) u[3] = (T) 0;
-    *reinterpret_cast<T *>(smem + ((m0 >> 16) + lds0)) = u[0];
-    *reinterpret_cast<T *>(smem + ((m1 >> 16) + lds0)) = u[1];
-    *reinterpret_cast<T *>(smem + ((m2 >> 16) + lds0)) = u[2];
+    *reinterpret_cast<T *>(smem + (m0 >> 16)) = u[0];
+    *reinterpret_cast<T *>(smem + (m1 >> 16)) = u[1];
+    *reinterpret_cast<T *>(smem + (m2 >> 16)) = u[2];
     *reinterpret_cast<T *>(smem + (u3_addr + lds0)) = u[3];
 }
 
@@ -683,7 +685,8 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
             for (int k = 0; k < 3; ++k) mem[p][k] = t.blk_mem[(size_t) k * t.G_pad + gs];
         }
     }
-    uint32_t ent[BP][ADMM_VK];  // list entries: LDS byte address of U[group][0] | "coefficient is -1" flags, row r at bit 31-r
+    uint32_t ent[BP][ADMM_VK];  // list entries: ABSOLUTE LDS byte address of U[group][0] | "coefficient is -1" flags, row r at bit 31-r
+    const uint32_t smem_abs = (uint32_t) (uintptr_t) smem;  // start of the dynamic LDS (behind the static words)
     uint32_t mlw_pk = 0;             // list length of (pass p, my wavefront) at bits 8p..8p+7
     uint32_t gen_pk = 0;             // bit p: (pass p, my wavefront) holds one- or two-variable checks
     // LDS byte address of my variable in pass p: its thread slot when the placement says so (cell_is_slot), otherwise read
@@ -706,7 +709,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
             inv[p] = inv_coef[p * L + l];
 #pragma unroll
             for (int k = 0; k < ADMM_VK; ++k)
-                if (k < admm_vk(p) && k < ml) ent[p][k] = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
+                if (k < admm_vk(p) && k < ml) ent[p][k] = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l] + smem_abs;  // (no carry into the flags: host check)
         }
     }
     mlw_pk = (uint32_t) __builtin_amdgcn_readfirstlane((int) mlw_pk);
@@ -776,27 +779,12 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                 if (p < t.n_vpass && ml > 0) {  // v-update (qp_admm.h:132-142); ml == 0: no variable of my wavefront here
                     T B = qreg[p];
                     const uint32_t v_cell = cell_slot ? 0u : (uint32_t) t.blk_cell[(uint32_t) (p * L) + l_o];
-#if ADMM_PREFETCH
                     {  // (entries past admm_vk(p) are never touched: the chain runs min(ml, admm_vk(p)) entries)
                         uint32_t ec[ADMM_VK];
 #pragma unroll
                         for (int k = 0; k < ADMM_VK; ++k) ec[k] = ent[p][k < admm_vk(p) ? k : 0];
-                        admm_v_chain(smem, ec, (uint32_t) (ml < admm_vk(p) ? ml : admm_vk(p)), lds0, k80, one_hi, B);
+                        admm_v_chain(ec, (uint32_t) (ml < admm_vk(p) ? ml : admm_vk(p)), k80, one_hi, B);
                     }
-#else
-#pragma unroll
-                    for (int k = 0; k < ADMM_VK; ++k)
-                        if (k < admm_vk(p) && k < ml) {
-                            const uint32_t e = ent[p][k];
-                            T ux, uy, uz, uw;
-                            admm_read_rows(smem, (e & 0xFFFFu) + lds0, ux, uy, uz, uw);
-                            B = X::fma(pm1(e), ux, B);
-                            B = X::fma(pm1(e << k1), uy, B);
-                            B = X::fma(pm1(e << k2), uz, B);
-                            B = B + uw;  // row 3 (x_i + x_j + x_h <= 2, qp_admm.h:52-57) has coefficient +1 for every member;
-                                         // one- and two-variable checks have no such row and keep u = 0 there
-                        }
-#endif
                     for (int k = admm_vk(p); k < ml; ++k) {  // lists longer than the register file holds
                         const uint32_t e = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
                         T ux, uy, uz, uw;
@@ -829,12 +817,12 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                 if (p < t.n_gpass) {
                     const uint32_t ty = (tys >> (2 * p)) & 3u;
                     const uint32_t u3 = u3_0 + (uint32_t) p * u3_step;
+                    uint32_t mo0 = mem[p][0], mo1 = mem[p][1], mo2 = mem[p][2];
+                    asm volatile("" : "+v"(mo0), "+v"(mo1), "+v"(mo2));
                     if ((gen_o >> p) & 1u) {  // wavefront-uniform
-                        if (ty != 0u)
-                            admm_group_update<T, EE, true>(smem, lds0, mem[p][0], mem[p][1], mem[p][2], u3, ty, mu, ylreg[p], sum2);
+                        if (ty != 0u) admm_group_update<T, EE, true>(smem, lds0, mo0, mo1, mo2, u3, ty, mu, ylreg[p], sum2);
                     } else {
-                        if (ty != 0u)
-                            admm_group_update<T, EE, false>(smem, lds0, mem[p][0], mem[p][1], mem[p][2], u3, ty, mu, ylreg[p], sum2);
+                        if (ty != 0u) admm_group_update<T, EE, false>(smem, lds0, mo0, mo1, mo2, u3, ty, mu, ylreg[p], sum2);
                     }
                 }
             it += 1;
@@ -1095,7 +1083,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         auto u_addr = [&](int gs, int row) {
             return u_base + (((uint32_t) gs >> 5) * 128u + (uint32_t) row * 32u + ((uint32_t) gs & 31u)) * ts;
         };
-        if (u_addr(t.U_slots, 0) + (uint32_t) t.nwords * 4 > 0xFFFFu) {
+        if (u_addr(t.U_slots, 0) + (uint32_t) t.nwords * 4 + 1024u > 0xFFFFu) {  // (+1 KiB: the kernel's static LDS words sit in front and are added to the 16-bit list addresses)
             err = "QP-ADMM frame state exceeds the 64 KiB the workgroup-per-frame kernel addresses";
             admm_device_destroy(d);
             return nullptr;
