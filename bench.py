@@ -58,8 +58,7 @@ PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE",
                       "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"]),
               # optional (a failure of this pass only drops the fp64 split of the QP-ADMM VALU estimate)
-              ("f64", ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
-                       "SQ_ACTIVE_INST_VALU"]))
+              ("f64", ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]))
 PMC_OPTIONAL = ("f64",)
 
 
@@ -503,6 +502,17 @@ def pmc_collect(a, budget_s):
         elif err:
             out["error"] = err
             break
+    # static instruction mix of the probed kernels, priced by operation class (tools/valu_mix.py): carried with the counters
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import valu_mix
+        mix = valu_mix.static_mix({item: pat for item, (pat, _) in PROBE_KERNEL.items()})
+        for item, m in mix.items():
+            out["items"][item].update({"STATIC_VALU_FULL_RATE": m["full_rate"], "STATIC_VALU_HALF_RATE": m["half_rate"],
+                                       "STATIC_VALU_TRANS": m["transcendental"],
+                                       "STATIC_CYC_PER_NON_TRANS": m["cycles_per_non_transcendental"]})
+    except Exception as e:  # the lower bound stands alone then
+        out.setdefault("notes", []).append("static instruction mix unavailable: %r" % (e,))
     out["seconds"] = time.time() - t_start
     return out
 
@@ -535,18 +545,19 @@ def roofline_fused(c, src, kms, F, bpf, fp64=False):
     lds = c.get("SQ_LDS_IDX_ACTIVE", 0.0) / sec / 1e9
     peak_valu, peak_lds = N_SIMD * NOMINAL_CLK_HZ / 1e9, N_CU * NOMINAL_CLK_HZ / 1e9
     fv, fl = valu / peak_valu, lds / peak_lds
-    # fp64 kernel: the time its wavefronts spent executing VALU instructions, measured (SQ_ACTIVE_INST_VALU, quad-cycles).
-    # A wavefront occupies its SIMD for 4 cycles per fp64 or 3-operand/shift/SDWA integer instruction and nothing of another
-    # wavefront overlaps it (tools/microbench/valu_op_rates: 4.2-4.4 cycles each at 5 wavefronts per SIMD), so for this kernel the
-    # sum IS the SIMD busy time; for the fp32 kernels it is not (two wavefronts' 2-cycle instructions share a quad), so
-    # there the priced instruction counts stay.
-    f_busy = None
-    if fp64 and c.get("SQ_ACTIVE_INST_VALU"):
-        f_busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / sec / 1e9 / peak_valu
-        if f_busy <= 1.0:
-            valu, fv_model, fv = f_busy * peak_valu, fv, f_busy
-        else:
-            f_busy = None
+    # The same counts priced with the kernel's own static mix of full-rate (2 cycles) and half-rate instructions (4 cycles:
+    # every fp64 operation, compares, min/max, selects on SGPR masks, left shifts, shift-adds, and-ors, SDWA/DPP, packed f16,
+    # ...; tools/valu_mix.py, per-operation costs from tools/microbench/valu_op_rates.hip).  An estimate (static, not
+    # dynamic, counts), reported as frac when it stays <= 1; the 2-cycle pricing remains as the guaranteed lower bound and
+    # "everything at 4 cycles" as the upper one.  (SQ_ACTIVE_INST_VALU is no help: it reads one quad-cycle per instruction
+    # whatever the instruction, 1.0004 x SQ_INSTS_VALU on the fp64 kernel and 1.07 x on the fp32 one.)
+    f_mix = None
+    if c.get("STATIC_CYC_PER_NON_TRANS"):
+        f_mix = ((nv - nt) * c["STATIC_CYC_PER_NON_TRANS"] + nt * CYC_TRANS) / sec / 1e9 / peak_valu
+    fv_lower = fv
+    f_upper = ((nv - nt) * 4.0 + nt * CYC_TRANS) / sec / 1e9 / peak_valu
+    if f_mix is not None and f_mix <= 1.0:
+        valu, fv = f_mix * peak_valu, f_mix
     traffic = None
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:   # rocprofv3 reports KiB; gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)
         traffic = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
@@ -558,14 +569,16 @@ def roofline_fused(c, src, kms, F, bpf, fp64=False):
               "lds_bank_conflict_share": (c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
               "wave_wait_share": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
               "valu_insts_per_launch": nv, "trans_insts_per_launch": nt, "f64_arith_insts_per_launch": n64,
-              "valu_busy_measured": f_busy is not None, "valu_issue_model_frac": (fv_model if f_busy is not None else fv),
+              "valu_issue_model_frac": fv_lower, "valu_issue_frac_by_op_class": f_mix, "valu_issue_upper_frac": min(f_upper, 1.0),
+              "frac_basis": ("instruction counts priced by operation class (static mix of the kernel: %d full-rate, %d half-rate, %d "
+                             "transcendental instructions)" % (c["STATIC_VALU_FULL_RATE"], c["STATIC_VALU_HALF_RATE"], c["STATIC_VALU_TRANS"])
+                             if (f_mix is not None and f_mix <= 1.0) else "instruction counts priced at 2 cycles (8 transcendental): lower bound"),
               "model": "VALU: (%s x other + %g x transcendental wave-instructions) / (1024 SIMDs x 2.4 GHz x kernel time)%s; "
                        "LDS: SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x kernel time); nominal clock, so both are lower bounds of the "
                        "utilisation at the clock actually sustained" % (("%g" % (CYC_VALU if (not fp64 or n64 is not None) else CYC_VALU_F64)), CYC_TRANS,
                                                                        (" — fp64 add/mul/fma (SQ_INSTS_VALU_*_F64) at 4 cycles, everything else at 2" if n64 is not None else
                                                                         " — every VALU op priced as fp64 (upper bound)") if fp64 else "")
-                       + ("; valu_issue_frac / frac of this fp64 kernel = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz x kernel time), "
-                          "the measured busy time (the priced count is kept as valu_issue_model_frac)" if f_busy is not None else "")})
+})
     return r
 
 

@@ -160,3 +160,20 @@ def test_admm_block_placement_quasi_cyclic(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     v = [int(x) for x in out.stdout.split()]
     assert v[0] == 0 and v[3:6] == v[6:9]
+
+
+def test_valu_mix_tool_prices_the_headline_kernels():
+    """tools/valu_mix.py (used by bench.py for roofline.frac): the static instruction mix of the probed kernels is found in the
+    built library and lies between the all-full-rate and all-half-rate prices"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import valu_mix
+    if not os.path.exists(valu_mix.LLVM + "/llvm-objdump"):
+        pytest.skip("no llvm-objdump in this image")
+    mix = valu_mix.static_mix({"bp": "bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", "admm": "admm_block_kernel<double, false, 3>"})
+    assert set(mix) == {"bp", "admm"}
+    for m in mix.values():
+        assert m["valu_static"] > 500 and 2.0 <= m["cycles_per_non_transcendental"] <= 4.0
+    assert mix["bp"]["transcendental"] > 50 and mix["admm"]["transcendental"] == 0
+    assert mix["admm"]["half_rate"] > mix["admm"]["full_rate"]   # fp64 arithmetic is all half-rate
