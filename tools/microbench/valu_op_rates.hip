@@ -59,13 +59,17 @@
     X(21, "v_mov_b64", asm volatile("v_mov_b64 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7])))                             \
     X(22, "v_exp_f32", asm volatile("v_exp_f32 %0, -%0" : "+v"(u[i])))                                                  \
     X(23, "v_pk_add_f16", asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(u[i]) : "v"(0x3c003c00u)))                      \
-    X(24, "v_pk_min_f16", asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(u[i]) : "v"(0x3c003c00u)))
+    X(24, "v_pk_min_f16", asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(u[i]) : "v"(0x3c003c00u)))                      \
+    X(47, "v_pk_fma_f32 (2 x fp32)", asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(p2a), "v"(p2b)))        \
+    X(48, "v_pk_mul_f32 (2 x fp32)", asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(p2a)))                      \
+    X(49, "v_pk_add_f32 (2 x fp32)", asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(p2b)))
 
 template <int MODE>
 __global__ void k(double *out, unsigned long long *stamps) {
     double a[8];
     uint32_t u[8];
     unsigned long long m[8] = {};
+    const double p2a = __longlong_as_double(0x3f7fbe773f7fbe77ll), p2b = __longlong_as_double(0x3a83126f3a83126fll);  // (0.999f, 0.999f), (1e-3f, 1e-3f)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         a[i] = threadIdx.x * 1e-3 + 1.0 + i;
