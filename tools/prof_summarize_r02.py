@@ -66,6 +66,16 @@ with open(os.path.join(out, "%s_summary.md" % tag), "w") as f:
     for r in rows[:14]:
         f.write("| `%s` | %s | %.3f | %.3f | %.3f | %s |\n" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6,
                                                           float(r["MaxNs"]) / 1e6, r["Percentage"]))
+    # the headline alone (`bench.py --no-extras`, the second run of tools/prof_stats_r02.sh): every launch of its kernel is a
+    # 50-sweep, 1M-frame launch, so the average duration here is the one to hold against `ms_per_step` / `roofline.kernel_ms`
+    hl = os.path.join(os.path.dirname(stats), "bench_headline_kernel_stats.csv")
+    if os.path.exists(hl):
+        shutil.copy(hl, os.path.join(out, "%s_bench_headline_kernel_stats.csv" % tag))
+        hrows = list(csv.DictReader(open(hl)))
+        f.write("\n## rocprofv3 --kernel-trace --stats of `bench.py --no-extras` (headline launches only)\n\n| kernel | calls | avg ms | min ms | max ms |\n|---|---|---|---|---|\n")
+        for r in hrows[:3]:
+            f.write("| `%s` | %s | %.3f | %.3f | %.3f |\n" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6))
+        f.write("\nbench.py, same sources: `ms_per_step` %.3f, `roofline.kernel_ms` %.3f (HIP events on the launch stream).\n" % (j["ms_per_step"], j["roofline"]["kernel_ms"]))
     if j.get("pmc", {}).get("items"):
         f.write("\n## counters, mean per launch\n\n")
         for item, c in j["pmc"]["items"].items():
