@@ -827,7 +827,12 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                 }
             it += 1;
             if (EE) {
-                sum2 = wave_sum(sum2);
+                // every term of the residual is a square: as soon as one lane's partial sum reaches eps the total does, and the
+                // wavefront can report "not below eps" (+inf) without the cross-lane fp64 sum (12 DPP moves, 4 adds, 8 lane
+                // reads) — the case of every sweep but the last few of a frame.  The stopping decision is unchanged: inf (or
+                // NaN) < eps is false exactly when the exact total >= eps (or NaN) is.
+                if (__ballot(sum2 >= eps_stop) != 0ull) sum2 = (T) INFINITY;
+                else sum2 = wave_sum(sum2);
                 if (lane == 0) red[wave] = sum2;
                 if (l < 4 && l >= (L >> 6)) red[l] = (T) 0;  // workgroups of fewer than 4 wavefronts
                 __syncthreads();
