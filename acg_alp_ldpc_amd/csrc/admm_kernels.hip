@@ -433,9 +433,16 @@ __global__ void __launch_bounds__(256) admm_fused_kernel(const AdmmDevTables t, 
             }
         }
         wave_sync();
-        sum2 = group_sum<L, T>(sum2);
+        // (as in admm_block_kernel: a lane whose partial sum of squares already reaches eps settles "not converged" for its
+        // frame; the fp64 reduction runs only when some frame of the wavefront has no such lane)
+        const bool big = group_any<L>(sum2 >= eps_stop, g);
         it += 1;
-        converged = (sum2 < eps_stop);
+        if (__ballot(!big) != 0ull) {
+            sum2 = group_sum<L, T>(sum2);
+            converged = (sum2 < eps_stop);
+        } else {
+            converged = false;
+        }
     }
 
     if (MC && l == 0 && acc_total) {
