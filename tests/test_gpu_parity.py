@@ -606,6 +606,13 @@ def test_config5_block_kernel_variants_agree_near_threshold(A, oracle):
         b2, k2, i2 = dec.decode_batch(H, y, snr)
         dec.close()
         assert (k0 == k2).all() and (b0 == b2).all() and (i0 == i2).all()
+        # the wave-group kernel forced onto this code (one frame per wavefront, 160 KB of LDS): its message array is past the
+        # 64 KiB the byte-offset index copy addresses, so this is the instance that reads the index table from memory
+        dec = make(lanes_per_frame=64)
+        assert dec.layout(H)["lanes_per_frame"] == 64
+        b3, k3, i3 = dec.decode_batch(H, y[:48], snr)
+        dec.close()
+        assert (k0[:48] == k3).all() and (b0[:48] == b3).all() and (i0[:48] == i3).all()
     ob, ook, oit = oracle.bp_decode(Hm, y[:8], snr, 60, threads=8)
     dec = A.BeliefPropagationDecoder(60)
     bits, ok, iters = dec.decode_batch(H, y[:8], snr)
