@@ -824,8 +824,8 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                 if (p < t.n_gpass) {
                     const uint32_t ty = (tys >> (2 * p)) & 3u;
                     const uint32_t u3 = u3_0 + (uint32_t) p * u3_step;
-                    uint32_t mo0 = mem[p][0], mo1 = mem[p][1], mo2 = mem[p][2];
-                    asm volatile("" : "+v"(mo0), "+v"(mo1), "+v"(mo2));
+                    asm volatile("" : "+v"(mem[p][0]), "+v"(mem[p][1]), "+v"(mem[p][2]));  // opaque in place: no copies
+                    const uint32_t mo0 = mem[p][0], mo1 = mem[p][1], mo2 = mem[p][2];
                     if ((gen_o >> p) & 1u) {  // wavefront-uniform
                         if (ty != 0u) admm_group_update<T, EE, true>(smem, lds0, mo0, mo1, mo2, u3, ty, mu, ylreg[p], sum2);
                     } else {
