@@ -116,6 +116,7 @@ struct AdmmDevice {
     int L = 64, f32 = 0, block = 256, frames_per_block = 4, grid_cap = 256;
     bool reg = false;  // row state in registers (ADMM_NGP variant)
     bool blockmode = false;  // workgroup-per-frame kernel
+    bool blk_lean = false;   // ... its instance without the general paths (see admm_block_kernel)
     const void *kernel[2] = {nullptr, nullptr};
     size_t lds_block = 0;
     bool guard = false;  // e_min*mu <= alpha  (qp_admm.h:108-114)
@@ -665,7 +666,11 @@ __device__ __forceinline__ void admm_group_update(unsigned char *smem, const uin
 
 // BP = passes (of blockDim.x constraint groups / variables) the register-resident structure is sized for; fewer passes
 // = fewer registers = more wavefronts per SIMD (launch bound: 4, 5, 6 workgroups of 4 wavefronts per CU for BP = 4, 3, 2).
-template <typename T, bool EE, int BP>
+// LEAN: the instance for problems that need none of the general paths inside the sweep — no one-/two-variable checks, every
+// list within the register-resident entries of its pass, V cell = thread slot (all true for the quasi-cyclic tuple placement
+// of H05 / optimalH).  The wavefronts of this kernel are bound by how many instructions they have to get through per sweep,
+// scalar tests and branches included, so the paths are compiled out, not branched around.
+template <typename T, bool EE, int BP, bool LEAN>
 __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? ADMM_OCC_F32 : 0)) admm_block_kernel(const AdmmDevTables t, const DecodeArgs a, const T alpha,
                                                               const T mu, const T eps_stop) {
     using X = AdmmVec<T>;
@@ -698,7 +703,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
     uint32_t gen_pk = 0;             // bit p: (pass p, my wavefront) holds one- or two-variable checks
     // LDS byte address of my variable in pass p: its thread slot when the placement says so (cell_is_slot), otherwise read
     // from the table once per sweep (ahead of the list, so the list hides the load); bit 8+p of tys = "I own a variable"
-    const bool cell_slot = t.cell_is_slot != 0;
+    const bool cell_slot = LEAN || t.cell_is_slot != 0;
     T inv[BP];
     const T *inv_coef = reinterpret_cast<const T *>(t.inv_coef);
 #pragma unroll
@@ -792,6 +797,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                         for (int k = 0; k < ADMM_VK; ++k) ec[k] = ent[p][k < admm_vk(p) ? k : 0];
                         admm_v_chain(ec, (uint32_t) (ml < admm_vk(p) ? ml : admm_vk(p)), k80, one_hi, B);
                     }
+                    if constexpr (!LEAN)
                     for (int k = admm_vk(p); k < ml; ++k) {  // lists longer than the register file holds
                         const uint32_t e = t.blk_list[(size_t) t.v_list_off[p] + (size_t) k * L + l];
                         T ux, uy, uz, uw;
@@ -826,7 +832,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                     const uint32_t u3 = u3_0 + (uint32_t) p * u3_step;
                     asm volatile("" : "+v"(mem[p][0]), "+v"(mem[p][1]), "+v"(mem[p][2]));  // opaque in place: no copies
                     const uint32_t mo0 = mem[p][0], mo1 = mem[p][1], mo2 = mem[p][2];
-                    if ((gen_o >> p) & 1u) {  // wavefront-uniform
+                    if (!LEAN && ((gen_o >> p) & 1u)) {  // wavefront-uniform
                         if (ty != 0u) admm_group_update<T, EE, true>(smem, lds0, mo0, mo1, mo2, u3, ty, mu, ylreg[p], sum2);
                     } else {
                         if (ty != 0u) admm_group_update<T, EE, false>(smem, lds0, mo0, mo1, mo2, u3, ty, mu, ylreg[p], sum2);
@@ -923,16 +929,20 @@ static const void *admm_kernel_ptr(int f32, int L, bool mc, bool reg) {
     return admm_ptr<double, 16, 0>(mc);
 }
 
-template <typename T, bool EE>
+template <typename T, bool EE, bool LEAN>
 static const void *admm_block_ptr_t(int passes) {
-    if (passes <= 2) return (const void *) admm_block_kernel<T, EE, 2>;
-    if (passes == 3) return (const void *) admm_block_kernel<T, EE, 3>;
-    return (const void *) admm_block_kernel<T, EE, 4>;
+    if (passes <= 2) return (const void *) admm_block_kernel<T, EE, 2, LEAN>;
+    if (passes == 3) return (const void *) admm_block_kernel<T, EE, 3, LEAN>;
+    return (const void *) admm_block_kernel<T, EE, 4, LEAN>;
 }
 
-static const void *admm_block_ptr(int f32, bool ee, int passes) {
-    if (f32) return ee ? admm_block_ptr_t<float, true>(passes) : admm_block_ptr_t<float, false>(passes);
-    return ee ? admm_block_ptr_t<double, true>(passes) : admm_block_ptr_t<double, false>(passes);
+static const void *admm_block_ptr(int f32, bool ee, int passes, bool lean) {
+    if (lean) {
+        if (f32) return ee ? admm_block_ptr_t<float, true, true>(passes) : admm_block_ptr_t<float, false, true>(passes);
+        return ee ? admm_block_ptr_t<double, true, true>(passes) : admm_block_ptr_t<double, false, true>(passes);
+    }
+    if (f32) return ee ? admm_block_ptr_t<float, true, false>(passes) : admm_block_ptr_t<float, false, false>(passes);
+    return ee ? admm_block_ptr_t<double, true, false>(passes) : admm_block_ptr_t<double, false, false>(passes);
 }
 
 template <typename T>
@@ -1168,6 +1178,11 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         t.cell_is_slot = 1;
         for (int sidx = 0; sidx < t.n_vpass * L; sidx++)
             if (blk_cell[sidx] >= 0 && blk_cell[sidx] != sidx) t.cell_is_slot = 0;
+        // the lean kernel instance (admm_block_kernel<..., LEAN>): nothing of the general paths is needed inside a sweep
+        d->blk_lean = t.cell_is_slot && !getenv("ACG_ADMM_NO_LEAN");
+        for (uint8_t g_ : blk_generic) d->blk_lean = d->blk_lean && g_ == 0;
+        for (int p_ = 0; p_ < t.n_vpass; p_++)
+            for (int w_ = 0; w_ < 4; w_++) d->blk_lean = d->blk_lean && blk_mlw[(size_t) p_ * 4 + w_] <= admm_vk(p_);
         ok = t.blk_mem && t.blk_list && t.blk_mlw && t.grp_type_slot && t.blk_generic && t.blk_cell;
     }
     t.grp_mem = (const uint32_t *) upload_vec(grp_mem, d->allocs, err);
@@ -1206,7 +1221,7 @@ AdmmDevice *admm_device_create(const Code &c, const acg_ldpc_params &p, int cu_c
         for (int ee = 0; ee < 2; ee++) {  // kernel[0]: fixed sweep count, kernel[1]: with the residual stopping rule
             const int mc = ee;
             const int passes = std::max(std::max(t.n_gpass, t.n_vpass), 2);
-            const void *kp = admm_block_ptr(d->f32, ee != 0, passes);
+            const void *kp = admm_block_ptr(d->f32, ee != 0, passes, d->blk_lean);
             d->kernel[mc] = kp;
             if (d->lds_block > 64 * 1024 &&
                 hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block) != hipSuccess) {
