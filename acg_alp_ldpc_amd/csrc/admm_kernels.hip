@@ -772,9 +772,9 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
         while (it < a.max_iter) {
             // Constants the compiler must not see through: everything derived from the register-resident tables
             // (addresses, +-1 patterns) would otherwise be hoisted out of the sweep loop into ~5 registers per entry.
-            uint32_t k80, k1, k2, lds0, one_hi, mlw_o = mlw_pk, gen_o = gen_pk;
-            asm volatile("s_mov_b32 %0, 0x80000000\n\ts_mov_b32 %1, 1\n\ts_mov_b32 %2, 2\n\ts_mov_b32 %3, 0"
-                         : "=s"(k80), "=s"(k1), "=s"(k2), "=s"(lds0));
+            uint32_t k80, k1 = 1, k2 = 2, lds0, one_hi, mlw_o = mlw_pk, gen_o = gen_pk;
+            asm volatile("s_mov_b32 %0, 0x80000000\n\ts_mov_b32 %1, 0" : "=s"(k80), "=s"(lds0));
+            if (!LEAN) asm volatile("s_mov_b32 %0, 1\n\ts_mov_b32 %1, 2" : "=s"(k1), "=s"(k2));  // (only the long-list path shifts by them)
             if (sizeof(T) == 8) asm volatile("v_mov_b32 %0, 0x3ff00000" : "=v"(one_hi));  // in a VGPR: (x & k80) | one_hi is one v_and_or_b32
             else asm volatile("v_mov_b32 %0, 1.0" : "=v"(one_hi));
             asm volatile("" : "+s"(mlw_o), "+s"(gen_o));
@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
 #pragma unroll
             for (int p = 0; p < BP; ++p) {
                 const int ml = (int) ((mlw_o >> (8 * p)) & 0xFFu);
-                if (p < t.n_vpass && ml > 0) {  // v-update (qp_admm.h:132-142); ml == 0: no variable of my wavefront here
+                if (ml > 0) {  // v-update (qp_admm.h:132-142); ml == 0: no variable of my wavefront here (or no such pass)
                     T B = qreg[p];
                     const uint32_t v_cell = cell_slot ? 0u : (uint32_t) t.blk_cell[(uint32_t) (p * L) + l_o];
                     {  // (entries past admm_vk(p) are never touched: the chain runs min(ml, admm_vk(p)) entries)
@@ -826,8 +826,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
             __syncthreads();
             T sum2 = (T) 0;  // residual, multiplier and slack update (qp_admm.h:144-159)
 #pragma unroll
-            for (int p = 0; p < BP; ++p)
-                if (p < t.n_gpass) {
+            for (int p = 0; p < BP; ++p) {  // (a pass the problem does not have: ty == 0 in every lane)
                     const uint32_t ty = (tys >> (2 * p)) & 3u;
                     const uint32_t u3 = u3_0 + (uint32_t) p * u3_step;
                     asm volatile("" : "+v"(mem[p][0]), "+v"(mem[p][1]), "+v"(mem[p][2]));  // opaque in place: no copies
