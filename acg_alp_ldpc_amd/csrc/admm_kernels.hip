@@ -498,6 +498,11 @@ template <> struct AdmmVec<double> {
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double clamp01(double x) {
+        double r;
+        asm("v_max_f64 %0, %1, %1 clamp" : "=v"(r) : "v"(x));
+        return r;
+    }
 };
 template <> struct AdmmVec<float> {
     typedef float v4 __attribute__((ext_vector_type(4)));
@@ -505,6 +510,11 @@ template <> struct AdmmVec<float> {
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
     static __device__ __forceinline__ float min(float a, float b) { return __builtin_fminf(a, b); }
+    static __device__ __forceinline__ float clamp01(float x) {
+        float r;
+        asm("v_max_f32 %0, %1, %1 clamp" : "=v"(r) : "v"(x));
+        return r;
+    }
 };
 
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v, const int ctrl_tag) {
@@ -676,6 +686,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
     using X = AdmmVec<T>;
     extern __shared__ __attribute__((aligned(32))) unsigned char smem[];
     const int L = blockDim.x;  // 128, 192 or 256 threads = one frame
+    __builtin_amdgcn_s_setreg((0 << 11) | (8 << 6) | 1, 0);  // hwreg(HW_REG_MODE, offset 8, width 1) = DX10_CLAMP := 0: the clamp modifier passes NaN (see the v-update)
     __shared__ T red[4];
     __shared__ unsigned long long fr_lds;
     const int l = threadIdx.x, lane = l & 63;
@@ -738,7 +749,6 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
         const int64_t frame = (int64_t) fr_lds;
         if (frame >= a.frames) break;
         // ---- start of a frame --------------------------------------------------------------------------------
-        bool q_nan = false;
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
             T q = (T) 0;  // auxiliaries: q = 0 (qp_admm.h:24)
@@ -750,11 +760,7 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                 }
             }
             qreg[p] = q + (alpha / 2);  // CalculateCoef, algo/algo.h:13-20; the v-update starts from q_i + alpha/2 (qp_admm.h:133)
-            q_nan |= (q != q);
         }
-        // A NaN symbol is the only way a NaN gets into a frame (v is clamped to [0, 1], so nothing overflows): such frames
-        // take the comparison form of the clamp below, which hands a NaN on exactly as std::max/std::min do.
-        const bool nan_frame = __syncthreads_or(q_nan) != 0;
         for (int w = l; w < t.V_pad; w += L) V[w] = (T) 0;
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
@@ -807,16 +813,11 @@ __global__ void __launch_bounds__(ADMM_BLK, ADMM_OCC - BP + (sizeof(T) == 4 ? AD
                         B = X::fma(pm1(e << k2), uz, B);
                         B = B + uw;
                     }
-                    // std::min(std::max(v, 0.0), 1.0) (qp_admm.h:140-141) as two instructions; they can differ from the
-                    // comparisons only in the sign of a zero, which no later value, comparison or decision depends on
-                    // (NaN aside: max/min drop a NaN, the comparisons keep it — frames with a NaN symbol go the long way)
-                    T v = B * inv[p];
-                    if (nan_frame) {  // workgroup-uniform
-                        v = (v < (T) 0) ? (T) 0 : v;  // std::max(v, 0.0)
-                        v = ((T) 1 < v) ? (T) 1 : v;  // std::min(v, 1.0)
-                    } else {
-                        v = X::min(X::max(v, (T) 0), (T) 1);
-                    }
+                    // std::min(std::max(v, 0.0), 1.0) (qp_admm.h:140-141) as ONE instruction, the output clamp of a v_max: it can
+                    // differ from the comparisons only in the sign of a zero, which no later value, comparison or decision
+                    // depends on — and a NaN passes through it as through std::max / std::min, because this kernel runs with
+                    // MODE.DX10_CLAMP cleared (set at its top; with the bit set the clamp would turn a NaN into 0)
+                    const T v = X::clamp01(B * inv[p]);
                     if ((tys >> (8 + p)) & 1u) {
                         const uint32_t va = cell_slot ? l_o * (uint32_t) sizeof(T) + (lds0 + (uint32_t) (p * L) * (uint32_t) sizeof(T)) : v_cell * (uint32_t) sizeof(T);
                         *reinterpret_cast<T *>(smem + va) = v;
