@@ -171,7 +171,7 @@ def test_valu_mix_tool_prices_the_headline_kernels():
     import valu_mix
     if not os.path.exists(valu_mix.LLVM + "/llvm-objdump"):
         pytest.skip("no llvm-objdump in this image")
-    mix = valu_mix.static_mix({"bp": "bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", "admm": "admm_block_kernel<double, false, 3>"})
+    mix = valu_mix.static_mix({"bp": "bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", "admm": "admm_block_kernel<double, false, 3, true>"})
     assert set(mix) == {"bp", "admm"}
     for m in mix.values():
         assert m["valu_static"] > 500 and 2.0 <= m["cycles_per_non_transcendental"] <= 4.0
