@@ -33,7 +33,7 @@ hipError_t phi_debug_launch(const void *x, void *out, int n, int f64, hipStream_
 hipError_t awgn_launch(float *y, int64_t frames, int n, int nwords, int64_t first_frame, uint64_t seed,
                        const uint32_t *cw_packed, int64_t n_cw, float sigma, hipStream_t s);
 
-const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, bool idxreg);
+const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, bool idxreg, bool regular);
 const void *bp_kernel_ptr_dbg(int f64, int L);
 const void *bp_block_kernel_ptr_dbg(int f64);
 const void *bp_pair_kernel_ptr(int L, bool regular);
@@ -628,7 +628,11 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
         for (int mc = 0; mc < 2; mc++) {
             // index table too large for LDS and variable degree <= 4: keep it in registers (decode kernel only)
             const bool idxreg = !idxlds && c.max_vdeg <= 4 && lay.n_vpass <= 12 && getenv("ACG_BP_NO_IDXREG") == nullptr;
-            const void *kp = bp_block_kernel_ptr(algo_b, d->f64, L, mc != 0, idxlds, idxreg);
+            // regular code (one check degree <= 8, one variable degree <= 4): the instance without the paths for anything else
+            bool regular_b = idxreg && c.max_cdeg >= 1 && c.max_cdeg <= 8 && c.max_vdeg >= 1 && c.max_vdeg <= 4 && getenv("ACG_BP_NO_REGULAR") == nullptr;
+            for (int i = 0; i < c.m && regular_b; i++) regular_b = (c.row_ptr[i + 1] - c.row_ptr[i] == c.max_cdeg);
+            for (int j = 0; j < c.n && regular_b; j++) regular_b = (c.col_ptr[j + 1] - c.col_ptr[j] == c.max_vdeg);
+            const void *kp = bp_block_kernel_ptr(algo_b, d->f64, L, mc != 0, idxlds, idxreg, regular_b);
             if (mc == 0) {
                 d->blk_idxlds = idxlds;
                 d->blk_idxreg = idxreg;

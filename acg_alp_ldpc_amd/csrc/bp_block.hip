@@ -11,7 +11,7 @@ namespace acg {
 
 // IDXREG: the variable-side index table in registers (variable degree <= 4, table too large for LDS): see var_phase_regs
 // DBG: tests only, see bp_fused_kernel
-template <typename T, int L, int ALGO, bool MC, bool IDXLDS, bool IDXREG = false, bool DBG = false>
+template <typename T, int L, int ALGO, bool MC, bool IDXLDS, bool IDXREG = false, bool DBG = false, bool REG = false>
 __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int MAXD = 8;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                 // them (no separate syndrome pass, one barrier less per sweep).  Its c->v output is wasted on the last trip.
 #ifdef ACG_BLOCK_STAMPS
                 const unsigned long long t0 = __builtin_readcyclecounter();
-                const bool myb = core.check_phase_syndrome(true);
+                const bool myb = core.template check_phase_syndrome<REG>(true);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_readcyclecounter();
                 bad = __syncthreads_or(myb ? 1 : 0) != 0;
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
                 st_chk += t1 - t0;
                 st_b1 += t2 - t1;
 #else
-                bad = __syncthreads_or(core.check_phase_syndrome(true) ? 1 : 0) != 0;
+                bad = __syncthreads_or(core.template check_phase_syndrome<REG>(true) ? 1 : 0) != 0;
 #endif
             } else {
                 bad = __syncthreads_or(core.syndrome_bad() ? 1 : 0) != 0;
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(L) bp_block_kernel(const BpTables t, const Dec
 #pragma unroll
                     for (int i = 0; i < 2 * NVP; ++i) asm volatile("" : "+v"(ir[i]));  // see BpCore::var_phase_regs
                 }
-                hard = IDXREG ? core.var_phase_regs(lr, ir, true) : core.var_phase_hard(lr, true);
+                hard = IDXREG ? core.template var_phase_regs<REG>(lr, ir, true) : core.var_phase_hard(lr, true);
             } else {
                 core.check_phase(true);
                 __syncthreads();
@@ -240,7 +240,12 @@ static const void *blk_ptr_l(int L, bool mc, bool idxlds) {
 }
 
 template <typename T, int ALGO>
-static const void *blk_ptr_idxreg(int L) {
+static const void *blk_ptr_idxreg(int L, bool regular) {
+    if (regular) {  // one check degree, one variable degree: the instance without the other paths (REG)
+        if (L == 256) return (const void *) bp_block_kernel<T, 256, ALGO, false, false, true, false, true>;
+        if (L == 1024) return (const void *) bp_block_kernel<T, 1024, ALGO, false, false, true, false, true>;
+        return nullptr;
+    }
     if (L == 256) return (const void *) bp_block_kernel<T, 256, ALGO, false, false, true>;
     if (L == 1024) return (const void *) bp_block_kernel<T, 1024, ALGO, false, false, true>;
     return nullptr;
@@ -258,14 +263,14 @@ const void *bp_block_kernel_ptr_dbg(int f64) {
 
 // workgroup-per-frame kernels exist for node degree <= 8, L in {256, 1024}; idxreg (decode only, no LDS index copy):
 // the index table lives in registers
-const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, bool idxreg) {
+const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, bool idxreg, bool regular) {
     if (idxreg && !mc && !idxlds) {
 #ifdef ACG_FAST_BUILD
         if (f64 || algo) return nullptr;
-        return blk_ptr_idxreg<float, 0>(L);
+        return blk_ptr_idxreg<float, 0>(L, regular);
 #else
-        if (algo == 0) return f64 ? blk_ptr_idxreg<double, 0>(L) : blk_ptr_idxreg<float, 0>(L);
-        return f64 ? blk_ptr_idxreg<double, 1>(L) : blk_ptr_idxreg<float, 1>(L);
+        if (algo == 0) return f64 ? blk_ptr_idxreg<double, 0>(L, regular) : blk_ptr_idxreg<float, 0>(L, regular);
+        return f64 ? blk_ptr_idxreg<double, 1>(L, regular) : blk_ptr_idxreg<float, 1>(L, regular);
 #endif
     }
 #ifdef ACG_FAST_BUILD
