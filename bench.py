@@ -426,10 +426,10 @@ def pmc_probe_child(a):
 
 
 PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
-    "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false", 1),
-    "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false>", 0),
+    "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 1),
+    "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true, true, 12, false>", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false>", 0),
     "ms_streamed": ("bp_streamed_ring_kernel<1, false>", 0), "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
-    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true>", 0),
+    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true>", 0),
 }
 
 
