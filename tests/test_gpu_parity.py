@@ -1048,3 +1048,45 @@ def test_published_fer_tables_statistically(A, pcm, oracle, matrix, gfile, alpha
                 assert p_ref - 0.03 < r.FER() < p_ref + half, (matrix, kind, snr, r.FER(), p_ref)
             else:
                 assert abs(r.FER() - p_ref) < half, (matrix, kind, snr, r.FER(), p_ref, half)
+
+
+def test_specialised_instances_equal_the_general_ones(A, pcm):
+    """The instances with general paths compiled out (QP-ADMM LEAN for the tuple placement of H05, BP REG for regular codes)
+    against the general instances of the same kernels (ACG_ADMM_NO_LEAN / ACG_BP_NO_REGULAR): bits, flags, sweep counts."""
+    H = pcm["H05"]
+    rng = np.random.default_rng(11)
+    y = 1.0 + 0.8 * rng.standard_normal((3000, H.n))
+    y[5, 7] = np.nan                      # the lean instance passes a NaN through its clamp (MODE.DX10_CLAMP cleared)
+    y[6, :4] = [0.0, -0.0, np.inf, -np.inf]
+    res = []
+    for env in (None, "ACG_ADMM_NO_LEAN"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            for eps in (0.0, 1e-5):
+                dec = A.QPADMMDecoder(1.95, 0.5, 60, eps)
+                res.append(dec.decode_batch(H, y, -1.0))
+                dec.close()
+        finally:
+            if env:
+                del os.environ[env]
+    for a, b in ((res[0], res[2]), (res[1], res[3])):
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    Hm = A.regular_ldpc(3000, 6000, 3, 6, seed=3)   # 36 KB of index table: the register-index instances, which have a REG twin
+    Hr = A.ParityCheckMatrix(Hm)
+    yr = 1.0 + 0.75 * rng.standard_normal((48, Hr.n))
+    out = []
+    for env in (None, "ACG_BP_NO_REGULAR"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            for make in (lambda: A.MinSumDecoder(40, 0.75, lanes_per_frame=1024), lambda: A.BeliefPropagationDecoder(40, lanes_per_frame=1024)):
+                dec = make()
+                assert dec.layout(Hr)["lanes_per_frame"] == 1024
+                out.append(dec.decode_batch(Hr, yr, 0.5))
+                dec.close()
+        finally:
+            if env:
+                del os.environ[env]
+    for a, b in ((out[0], out[2]), (out[1], out[3])):
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
