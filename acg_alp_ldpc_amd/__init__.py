@@ -5,7 +5,7 @@ Only the hot path of GreatDrake/acg-alp-ldpc is here: BP (algo/bp.h
 implemented as hand-written HIP kernels for gfx950 in csrc/ behind the C ABI of include/acg_ldpc.h.
 """
 from ._lib import (ENGINE_AUTO, ENGINE_FUSED, ENGINE_STREAMED, PREC_DEFAULT, PREC_F16, PREC_F32, PREC_F64,  # noqa: F401
-                   LdpcError, build, lib)
+                   SCHEDULE_FLOODING, SCHEDULE_LAYERED, LdpcError, build, lib)
 from .channel import gen_random_codewords, llr, llr_variance, transmit_frames  # noqa: F401
 from .code import ParityCheckMatrix  # noqa: F401
 from .codes import regular_ldpc  # noqa: F401

@@ -22,7 +22,7 @@ class Params(C.Structure):
     _fields_ = [("algo", C.c_int32), ("max_iter", C.c_int32), ("alpha", C.c_double), ("mu", C.c_double),
                 ("eps_stop", C.c_double), ("ms_scale", C.c_double), ("early_exit", C.c_int32),
                 ("precision", C.c_int32), ("device", C.c_int32), ("lanes_per_frame", C.c_int32),
-                ("engine", C.c_int32), ("fast_setup", C.c_int32)]
+                ("engine", C.c_int32), ("fast_setup", C.c_int32), ("schedule", C.c_int32)]
 
 
 class McCfg(C.Structure):
@@ -40,6 +40,7 @@ ALGO_BP, ALGO_MINSUM, ALGO_QPADMM = 0, 1, 2
 PREC_DEFAULT, PREC_F64, PREC_F32, PREC_F16 = 0, 1, 2, 3
 NOISE_DEVICE_PHILOX, NOISE_HOST_MT19937 = 0, 1
 ENGINE_AUTO, ENGINE_FUSED, ENGINE_STREAMED = 0, 1, 2
+SCHEDULE_FLOODING, SCHEDULE_LAYERED = 0, 1
 
 # every symbol include/acg_ldpc.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -66,6 +67,7 @@ SYMBOLS = {
     "acg_ldpc_decoder_sync": (C.c_int, [_vp]),
     "acg_ldpc_decoder_last_kernel_ms": (C.c_float, [_vp]),
     "acg_ldpc_decoder_layout": (None, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "acg_ldpc_decoder_describe": (_i32, [_vp, C.c_char_p, _i32]),
     "acg_ldpc_mc_run": (C.c_int, [_vp, C.POINTER(McCfg), C.POINTER(McResult)]),
     "acg_ldpc_mc_merge": (None, [C.POINTER(McResult), C.POINTER(McResult)]),
     "acg_ldpc_gen_codewords": (C.c_int, [_vp, _i32, _i32, C.c_uint32, _i64, _vp]),

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <string>
@@ -63,6 +64,24 @@ bool admm_device_unfused_mc(const AdmmDevice *d, const int32_t **row_ptr, const 
         }                                                                                       \
     } while (0)
 
+// No C++ exception may cross the extern "C" boundary (std::bad_alloc from a vector, std::system_error from std::thread, ...):
+// every entry point that can throw runs its body through guarded() and reports an error code + message instead.
+template <class F>
+static int guarded(F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory");
+        return 12;
+    } catch (const std::exception &e) {
+        set_error(std::string("internal exception: ") + e.what());
+        return 13;
+    } catch (...) {
+        set_error("internal exception");
+        return 13;
+    }
+}
+
 template <typename T>
 static int upload(const std::vector<T> &h, T **d, size_t min_elems = 1) {
     size_t n = std::max(h.size(), min_elems);
@@ -89,6 +108,7 @@ public:
     int size() const { return (int) th_.size(); }
     // fn(part, parts) on every worker thread; returns when all are done
     void run_all(const std::function<void(int, int)> &fn) {
+        std::lock_guard<std::mutex> one(call_mu_);   // the pool is shared by every handle of the process: one job at a time
         std::unique_lock<std::mutex> lk(mu_);
         fn_ = &fn;
         pending_ = (int) th_.size();
@@ -118,13 +138,26 @@ private:
         }
     }
     std::vector<std::thread> th_;
-    std::mutex mu_;
+    std::mutex mu_, call_mu_;
     std::condition_variable cv_, done_;
     const std::function<void(int, int)> *fn_ = nullptr;
     uint64_t gen_ = 0;
     int pending_ = 0;
     bool stop_ = false;
 };
+
+// ONE pool per process, created the first time a batch is large enough to use it (>= 4096 frames): a caller that hands a new
+// H to every decode — the reference's optimize_H loop, one decoder handle per proposal — must not collect threads per handle.
+static HostPool *host_pool() {
+    static std::mutex mu;
+    static HostPool *pool = nullptr;   // intentionally never destroyed (worker threads must not be joined from a static destructor)
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pool) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        pool = new HostPool((int) std::max(2u, std::min(16u, hc ? hc / 2 : 2u)));
+    }
+    return pool;
+}
 
 // Double-buffered staging of acg_ldpc_decode_batch / _f32: while the GPU works on chunk c (H2D, kernel, D2H on stream c % 2)
 // the host threads fill the pinned buffer of chunk c + 1 and unpack chunk c - 1.
@@ -138,7 +171,6 @@ struct HostPipe {
     unsigned char *dev_out[NBUF] = {};
     hipStream_t stream[NBUF] = {};
     hipEvent_t done[NBUF] = {};
-    HostPool *pool = nullptr;
     void release() {
         for (int b = 0; b < NBUF; b++) {
             if (pin_y[b]) (void) hipHostFree(pin_y[b]);
@@ -156,7 +188,6 @@ struct HostPipe {
             if (done[b]) (void) hipEventDestroy(done[b]);
             if (stream[b]) (void) hipStreamDestroy(stream[b]);
         }
-        delete pool;
     }
 };
 
@@ -174,7 +205,6 @@ struct acg_ldpc_decoder {
     int device = 0;
     int cu_count = 256;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     std::mutex mu;
     std::string name;
@@ -196,6 +226,7 @@ struct acg_ldpc_decoder {
     const void *skernel = nullptr;
     const void *sring = nullptr;  // LDS-DMA ring variant (fp32), null = not available for this code
     int sring_per_cu = 2;
+    bool sring_nt = false;  // ring instance with non-temporal slab accesses (slabs beyond the Infinity Cache)
     uint32_t *sws = nullptr;
     int sgrid = 0;
     // ADMM
@@ -219,8 +250,11 @@ struct acg_ldpc_decoder {
     // tile hand-out of the kernels), so launches of one handle that overlap on different streams never share one.
     // ring_ev[k] is recorded behind the launch that used slot k; the next user of the slot — and, for the streamed
     // engine, whose HBM slabs belong to the handle, every launch on a different stream — waits on it on the device.
+    // Timing: every launch also owns the (start, stop) event pair of its slot, so two launches of one handle in flight on
+    // two streams never pair each other's events; ring_ev[k] IS the stop event of slot k.
     static constexpr int WORK_RING = 32;
     unsigned long long *work_ring = nullptr;
+    hipEvent_t ring_ev0[WORK_RING] = {};
     hipEvent_t ring_ev[WORK_RING] = {};
     bool ring_used[WORK_RING] = {};
     uint64_t launch_seq = 0;
@@ -253,7 +287,7 @@ int acg_ldpc_device_available(void) {
 }
 
 // ---------------------------------------------------------------- code
-int acg_ldpc_code_from_dense(const uint8_t *H, int32_t m, int32_t n, acg_ldpc_code **out) {
+static int acg_ldpc_code_from_dense_impl(const uint8_t *H, int32_t m, int32_t n, acg_ldpc_code **out) {
     if (!H || !out) {
         set_error("null argument");
         return 1;
@@ -267,7 +301,11 @@ int acg_ldpc_code_from_dense(const uint8_t *H, int32_t m, int32_t n, acg_ldpc_co
     return 0;
 }
 
-int acg_ldpc_code_load_txt(const char *path, acg_ldpc_code **out) {
+int acg_ldpc_code_from_dense(const uint8_t *H, int32_t m, int32_t n, acg_ldpc_code **out) {
+    return guarded([&] { return acg_ldpc_code_from_dense_impl(H, m, n, out); });
+}
+
+static int acg_ldpc_code_load_txt_impl(const char *path, acg_ldpc_code **out) {
     if (!path || !out) {
         set_error("null argument");
         return 1;
@@ -278,12 +316,20 @@ int acg_ldpc_code_load_txt(const char *path, acg_ldpc_code **out) {
     return acg_ldpc_code_from_dense(H.data(), m, n, out);
 }
 
-int acg_ldpc_code_save_txt(const acg_ldpc_code *code, const char *path) {
+int acg_ldpc_code_load_txt(const char *path, acg_ldpc_code **out) {
+    return guarded([&] { return acg_ldpc_code_load_txt_impl(path, out); });
+}
+
+static int acg_ldpc_code_save_txt_impl(const acg_ldpc_code *code, const char *path) {
     if (!code || !path) {
         set_error("null argument");
         return 1;
     }
     return code_write_txt(code->c, path) ? 0 : 2;
+}
+
+int acg_ldpc_code_save_txt(const acg_ldpc_code *code, const char *path) {
+    return guarded([&] { return acg_ldpc_code_save_txt_impl(code, path); });
 }
 
 void acg_ldpc_code_destroy(acg_ldpc_code *code) { delete code; }
@@ -308,7 +354,7 @@ void acg_ldpc_code_admm_shape(const acg_ldpc_code *code, int32_t *n_var, int32_t
     if (e_max) *e_max = a.e_max;
 }
 
-int acg_ldpc_code_generator(const acg_ldpc_code *code, uint8_t *G) {
+static int acg_ldpc_code_generator_impl(const acg_ldpc_code *code, uint8_t *G) {
     if (!code || !G) {
         set_error("null argument");
         return 2;
@@ -318,6 +364,10 @@ int acg_ldpc_code_generator(const acg_ldpc_code *code, uint8_t *G) {
         return 2;
     }
     return code_generator(code->c, G) ? 0 : 1;
+}
+
+int acg_ldpc_code_generator(const acg_ldpc_code *code, uint8_t *G) {
+    return guarded([&] { return acg_ldpc_code_generator_impl(code, G); });
 }
 
 int acg_ldpc_code_is_codeword(const acg_ldpc_code *code, const uint8_t *bits) {
@@ -414,6 +464,7 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
         const size_t slab_bytes = ((size_t) (c.E + c.n) * 64 * ts + (size_t) vt.size() * 64);
         bool nt = slab_bytes * 3 * (size_t) d->cu_count > ((size_t) 256 << 20);
         if (getenv("ACG_STREAM_NT")) nt = atoi(getenv("ACG_STREAM_NT")) != 0;  // developer A/B only
+        d->sring_nt = nt;
         d->sring = bp_streamed_ring_ptr((d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0, nt);
         HIP_OK(hipFuncSetAttribute(d->sring, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
         hb_bytes = std::max(hb_bytes, (size_t) vt.size() * 64);  // ring engine: one byte per (variable task, frame)
@@ -687,7 +738,7 @@ static int decoder_setup_bp(acg_ldpc_decoder *d) {
     return 0;
 }
 
-int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *params, acg_ldpc_decoder **out) {
+static int acg_ldpc_decoder_create_impl(const acg_ldpc_code *code, const acg_ldpc_params *params, acg_ldpc_decoder **out) {
     if (!code || !params || !out) {
         set_error("null argument");
         return 1;
@@ -701,7 +752,10 @@ int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *pa
         set_error("no HIP device available: libacg_ldpc_hip has no CPU fallback");
         return 20;
     }
-    auto *d = new acg_ldpc_decoder();
+    // owned until handed out: an exception or an error below releases the streams, events and device memory made so far
+    struct Drop { void operator()(acg_ldpc_decoder *x) const { acg_ldpc_decoder_destroy(x); } };
+    std::unique_ptr<acg_ldpc_decoder, Drop> own(new acg_ldpc_decoder());
+    acg_ldpc_decoder *d = own.get();
     d->c = code->c;
     d->p = *params;
     int dev = params->device;
@@ -710,7 +764,6 @@ int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *pa
     }
     if (dev >= ndev) {
         set_error("device ordinal out of range");
-        delete d;
         return 1;
     }
     d->device = dev;
@@ -721,13 +774,12 @@ int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *pa
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("hipGetDeviceProperties failed"); rc = 10; break; }
         d->cu_count = prop.multiProcessorCount;
         if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = 10; break; }
-        if (hipEventCreate(&d->ev0) != hipSuccess || hipEventCreate(&d->ev1) != hipSuccess) { set_error("hipEventCreate failed"); rc = 10; break; }
         if (hipMalloc((void **) &d->counters, sizeof(unsigned long long) * MC_NCOUNTERS) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
         if (hipMalloc((void **) &d->work_ring, sizeof(unsigned long long) * acg_ldpc_decoder::WORK_RING) != hipSuccess) { set_error("hipMalloc failed"); rc = 10; break; }
         {
             bool evok = true;
             for (int k = 0; k < acg_ldpc_decoder::WORK_RING; k++)
-                evok = evok && hipEventCreateWithFlags(&d->ring_ev[k], hipEventDisableTiming) == hipSuccess;
+                evok = evok && hipEventCreate(&d->ring_ev0[k]) == hipSuccess && hipEventCreate(&d->ring_ev[k]) == hipSuccess;
             if (!evok) { set_error("hipEventCreate failed"); rc = 10; break; }
         }
         if (params->algo == ACG_LDPC_QPADMM) {
@@ -743,12 +795,13 @@ int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *pa
             rc = 1;
         }
     } while (0);
-    if (rc) {
-        acg_ldpc_decoder_destroy(d);
-        return rc;
-    }
-    *out = d;
+    if (rc) return rc;
+    *out = own.release();
     return 0;
+}
+
+int acg_ldpc_decoder_create(const acg_ldpc_code *code, const acg_ldpc_params *params, acg_ldpc_decoder **out) {
+    return guarded([&] { return acg_ldpc_decoder_create_impl(code, params, out); });
 }
 
 void acg_ldpc_decoder_destroy(acg_ldpc_decoder *d) {
@@ -767,10 +820,10 @@ void acg_ldpc_decoder_destroy(acg_ldpc_decoder *d) {
     if (d->cw_dev) (void) hipFree(d->cw_dev);
     if (d->counters) (void) hipFree(d->counters);
     if (d->work_ring) (void) hipFree(d->work_ring);
-    for (int k = 0; k < acg_ldpc_decoder::WORK_RING; k++)
+    for (int k = 0; k < acg_ldpc_decoder::WORK_RING; k++) {
+        if (d->ring_ev0[k]) (void) hipEventDestroy(d->ring_ev0[k]);
         if (d->ring_ev[k]) (void) hipEventDestroy(d->ring_ev[k]);
-    if (d->ev0) (void) hipEventDestroy(d->ev0);
-    if (d->ev1) (void) hipEventDestroy(d->ev1);
+    }
     if (d->stream) (void) hipStreamDestroy(d->stream);
     delete d;
 }
@@ -787,6 +840,40 @@ void acg_ldpc_decoder_layout(const acg_ldpc_decoder *d, int32_t *lds_bytes_per_f
     if (lanes_per_frame) *lanes_per_frame = d->L;
     if (frames_per_block) *frames_per_block = d->frames_per_block;
     if (grid_blocks) *grid_blocks = d->grid_cap[0];
+}
+
+// one line naming what this handle launches (diagnostics: bench.py records it next to every timed leg)
+static std::string describe(const acg_ldpc_decoder *d) {
+    char b[512];
+    const char *algo = d->p.algo == ACG_LDPC_QPADMM ? "qpadmm" : (d->p.algo == ACG_LDPC_BP_MINSUM ? "minsum" : "sum-product");
+    if (d->admm) {
+        int lds = 0, L = 0, fpb = 0, grid = 0;
+        admm_device_layout(d->admm, &lds, &L, &fpb, &grid);
+        snprintf(b, sizeof b, "%s engine=lds lanes_per_frame=%d frames_per_block=%d lds_bytes_per_frame=%d grid_cap=%d", algo, L, fpb, lds, grid);
+    } else if (d->streamed) {
+        const size_t slab = (size_t) d->stab.ws_words_per_wave * 4;
+        snprintf(b, sizeof b, "%s engine=streamed kernel=%s%s f64=%d slab_bytes=%zu slabs=%d workspace_bytes=%zu workgroups_per_cu=%d schedule=%s",
+                 algo, d->sring ? "bp_streamed_ring_kernel" : "bp_streamed_kernel", d->sring ? (d->sring_nt ? "<NT>" : "<default-policy>") : "",
+                 d->f64, slab, d->sgrid, slab * (size_t) d->sgrid, d->sring ? d->sring_per_cu : 2, "flooding");
+    } else {
+        snprintf(b, sizeof b, "%s engine=fused kernel=%s lanes_per_frame=%d f64=%d block=%d frames_per_block=%d lds_block=%zu grid_cap=%d "
+                               "idx_lds=%d idx_reg=%d schedule=%s",
+                 algo, d->pair ? "bp_pair_kernel" : (d->variant < 0 ? "bp_block_kernel" : "bp_fused_kernel"), d->L, d->f64, d->block,
+                 d->frames_per_block, d->lds_block, d->grid_cap[0], d->variant < 0 ? (int) d->blk_idxlds : (d->variant > 0), (int) d->blk_idxreg,
+                 d->p.schedule == ACG_LDPC_SCHEDULE_LAYERED ? "layered" : "flooding");
+    }
+    return b;
+}
+
+int32_t acg_ldpc_decoder_describe(const acg_ldpc_decoder *d, char *buf, int32_t cap) {
+    if (!d) return 0;
+    const std::string s = describe(d);
+    if (buf && cap > 0) {
+        const size_t k = std::min<size_t>(s.size(), (size_t) cap - 1);
+        std::memcpy(buf, s.data(), k);
+        buf[k] = 0;
+    }
+    return (int32_t) s.size() + 1;
 }
 
 static void fill_channel(DecodeArgs &a, double snr) {
@@ -814,7 +901,7 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
     HIP_OK(hipMemsetAsync(stamp_buf, 0, 16 * 5 * sizeof(unsigned long long), s));
     a.dbg_post = stamp_buf;
 #endif
-    HIP_OK(hipEventRecord(d->ev0, s));
+    HIP_OK(hipEventRecord(d->ring_ev0[slot], s));
     if (d->admm) {
         std::string err;
         hipError_t e = admm_launch(d->admm, a, s, err);
@@ -845,7 +932,7 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         int grid = (int) std::min<int64_t>(blocks, d->grid_cap[mc]);
         HIP_OK(bp_launch(d->kernel[mc], d->tab, a, grid, d->block, d->lds_block, s));
     }
-    HIP_OK(hipEventRecord(d->ev1, s));
+    HIP_OK(hipEventRecord(d->ring_ev[slot], s));   // stop event of this launch = the event later users of the slot wait on
 #ifdef ACG_BLOCK_STAMPS
     if (!d->admm && !d->streamed && getenv("ACG_STAMPS")) {
         unsigned long long h[16 * 5];
@@ -858,7 +945,6 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
                         (double) h[w * 5 + 3] / h[w * 5 + 4], h[w * 5 + 4]);
     }
 #endif
-    HIP_OK(hipEventRecord(d->ring_ev[slot], s));
     d->ring_used[slot] = true;
     d->last_slot = slot;
     d->last_stream = s;
@@ -866,7 +952,7 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
     return 0;
 }
 
-int acg_ldpc_decode_batch_dev(acg_ldpc_decoder *d, const void *y_dev, int32_t y_is_f64, int64_t frames, double snr,
+static int acg_ldpc_decode_batch_dev_impl(acg_ldpc_decoder *d, const void *y_dev, int32_t y_is_f64, int64_t frames, double snr,
                               uint32_t *bits_dev, uint8_t *ok_dev, int32_t *iters_dev, void *stream) {
     if (!d) {
         set_error("null decoder");
@@ -888,6 +974,11 @@ int acg_ldpc_decode_batch_dev(acg_ldpc_decoder *d, const void *y_dev, int32_t y_
     a.out_iters = iters_dev;
     a.mc = 0;
     return launch_decode(d, a, stream ? (hipStream_t) stream : d->stream);
+}
+
+int acg_ldpc_decode_batch_dev(acg_ldpc_decoder *d, const void *y_dev, int32_t y_is_f64, int64_t frames, double snr,
+                              uint32_t *bits_dev, uint8_t *ok_dev, int32_t *iters_dev, void *stream) {
+    return guarded([&] { return acg_ldpc_decode_batch_dev_impl(d, y_dev, y_is_f64, frames, snr, bits_dev, ok_dev, iters_dev, stream); });
 }
 
 static int ensure_staging(acg_ldpc_decoder *d, int64_t frames) {
@@ -912,16 +1003,19 @@ static int ensure_staging(acg_ldpc_decoder *d, int64_t frames) {
 
 static int ensure_pipe(acg_ldpc_decoder *d, int64_t chunk, size_t y_bytes) {
     if (!d->pipe) {
-        d->pipe = new HostPipe();
+        // built completely before it is published in the handle: a half-made pipe must never be seen by a later call
+        std::unique_ptr<HostPipe> np(new HostPipe());
         for (int b = 0; b < HostPipe::NBUF; b++) {
-            HIP_OK(hipStreamCreateWithFlags(&d->pipe->stream[b], hipStreamNonBlocking));
-            HIP_OK(hipEventCreateWithFlags(&d->pipe->done[b], hipEventDisableTiming));
+            HIP_OK(hipStreamCreateWithFlags(&np->stream[b], hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&np->done[b], hipEventDisableTiming));
         }
-        const unsigned hc = std::thread::hardware_concurrency();
-        d->pipe->pool = new HostPool((int) std::max(2u, std::min(16u, hc ? hc / 2 : 2u)));
+        d->pipe = np.release();
     }
     HostPipe &P = *d->pipe;
-    if (chunk <= P.chunk && y_bytes <= P.y_bytes) return 0;
+    // keep the buffers while they fit and are not grossly oversized for what is asked now (a 1M-frame batch followed by
+    // single-frame decode() calls must not pin hundreds of MB for good)
+    const size_t want = (size_t) chunk * y_bytes, have = (size_t) P.chunk * P.y_bytes;
+    if (chunk <= P.chunk && y_bytes <= P.y_bytes && (have <= ((size_t) 32 << 20) || have <= 16 * want)) return 0;
     P.release();
     const int nwords = (d->c.n + 31) / 32;
     for (int b = 0; b < HostPipe::NBUF; b++) {
@@ -933,6 +1027,14 @@ static int ensure_pipe(acg_ldpc_decoder *d, int64_t chunk, size_t y_bytes) {
     P.chunk = chunk;
     P.y_bytes = y_bytes;
     return 0;
+}
+
+// frames per chunk of the pipelined host path: bounded by BYTES (256 MiB of symbols per staging buffer), not by a frame
+// count — 65536 frames of the 10 000-symbol code in doubles would pin 2 x 5.2 GB of host memory and as much HBM per handle
+static int64_t host_chunk_frames(int64_t frames, size_t y_bytes) {
+    const int64_t by_bytes = (int64_t) (((size_t) 256 << 20) / std::max<size_t>(y_bytes, 1));
+    const int64_t cap = std::max<int64_t>(1024, std::min<int64_t>(1 << 16, by_bytes));
+    return std::min<int64_t>(frames, cap);
 }
 
 // packed words -> one byte per bit, 8 bits at a time through a 256-entry table
@@ -963,12 +1065,13 @@ static int decode_batch_host(acg_ldpc_decoder *d, const void *y, int elem, int64
                              int32_t *iters) {
     const int n = d->c.n, nwords = (n + 31) / 32;
     const size_t y_bytes = (size_t) n * elem;
-    // small batches (single frames: the reference's decode()) take one chunk; large ones ~64k frames per chunk
-    const int64_t chunk = std::min<int64_t>(frames, 1 << 16);
+    // small batches (single frames: the reference's decode()) take one chunk; large ones <= 64k frames / 256 MiB per chunk
+    const int64_t chunk = host_chunk_frames(frames, y_bytes);
     if (int rc = ensure_pipe(d, chunk, y_bytes)) return rc;
     HostPipe &P = *d->pipe;
     const int64_t nchunks = (frames + chunk - 1) / chunk;
     const bool threads = frames >= 4096;  // tiny batches: the hand-off to the pool costs more than the copy
+    HostPool *pool = threads ? host_pool() : nullptr;   // process-wide, created on first use
     auto chunk_frames = [&](int64_t c) { return std::min(chunk, frames - c * chunk); };
     auto pack = [&](int64_t c) {
         const int b = (int) (c % HostPipe::NBUF);
@@ -980,7 +1083,7 @@ static int decode_batch_host(acg_ldpc_decoder *d, const void *y, int elem, int64
             std::memcpy(dst, src, total);
             return;
         }
-        P.pool->run_all([&](int part, int parts) {
+        pool->run_all([&](int part, int parts) {
             const size_t lo = total * part / parts / 64 * 64, hi = (part + 1 == parts) ? total : total * (part + 1) / parts / 64 * 64;
             std::memcpy(dst + lo, src + lo, hi - lo);
         });
@@ -1014,7 +1117,7 @@ static int decode_batch_host(acg_ldpc_decoder *d, const void *y, int elem, int64
             unpack_bits(pbits, nwords, n, fc, bits + (size_t) f0 * n);
             return 0;
         }
-        P.pool->run_all([&](int part, int parts) {
+        pool->run_all([&](int part, int parts) {
             const int64_t lo = fc * part / parts, hi = fc * (part + 1) / parts;
             unpack_bits(pbits + (size_t) lo * nwords, nwords, n, hi - lo, bits + (size_t) (f0 + lo) * n);
         });
@@ -1035,7 +1138,7 @@ static int decode_batch_host(acg_ldpc_decoder *d, const void *y, int elem, int64
     return collect(nchunks - 1);
 }
 
-int acg_ldpc_decode_batch(acg_ldpc_decoder *d, const double *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
+static int acg_ldpc_decode_batch_impl(acg_ldpc_decoder *d, const double *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
                           int32_t *iters) {
     if (!d) {
         set_error("null decoder");
@@ -1051,7 +1154,12 @@ int acg_ldpc_decode_batch(acg_ldpc_decoder *d, const double *y, int64_t frames, 
     return decode_batch_host(d, y, 8, frames, snr, bits, ok, iters);
 }
 
-int acg_ldpc_decode_batch_f32(acg_ldpc_decoder *d, const float *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
+int acg_ldpc_decode_batch(acg_ldpc_decoder *d, const double *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
+                          int32_t *iters) {
+    return guarded([&] { return acg_ldpc_decode_batch_impl(d, y, frames, snr, bits, ok, iters); });
+}
+
+static int acg_ldpc_decode_batch_f32_impl(acg_ldpc_decoder *d, const float *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
                               int32_t *iters) {
     if (!d) {
         set_error("null decoder");
@@ -1067,6 +1175,11 @@ int acg_ldpc_decode_batch_f32(acg_ldpc_decoder *d, const float *y, int64_t frame
     return decode_batch_host(d, y, 4, frames, snr, bits, ok, iters);
 }
 
+int acg_ldpc_decode_batch_f32(acg_ldpc_decoder *d, const float *y, int64_t frames, double snr, uint8_t *bits, uint8_t *ok,
+                              int32_t *iters) {
+    return guarded([&] { return acg_ldpc_decode_batch_f32_impl(d, y, frames, snr, bits, ok, iters); });
+}
+
 int acg_ldpc_decoder_sync(acg_ldpc_decoder *d) {
     if (!d) return 1;
     HIP_OK(hipSetDevice(d->device));
@@ -1075,11 +1188,17 @@ int acg_ldpc_decoder_sync(acg_ldpc_decoder *d) {
 }
 
 float acg_ldpc_decoder_last_kernel_ms(acg_ldpc_decoder *d) {
-    if (!d || !d->ev_valid) return -1.0f;
+    if (!d) return -1.0f;
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (!d->ev_valid || d->last_slot < 0) return -1.0f;
+        slot = d->last_slot;
+    }
     (void) hipSetDevice(d->device);
-    if (hipEventSynchronize(d->ev1) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(d->ring_ev[slot]) != hipSuccess) return -1.0f;
     float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, d->ev0, d->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, d->ring_ev0[slot], d->ring_ev[slot]) != hipSuccess) return -1.0f;
     return ms;
 }
 
@@ -1194,7 +1313,7 @@ static int mc_run_host_noise(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, ac
     return 0;
 }
 
-int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc_result *res) {
+static int acg_ldpc_mc_run_impl(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc_result *res) {
     if (!d || !cfg || !res) {
         set_error("null argument");
         return 1;
@@ -1242,12 +1361,13 @@ int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc
             a.out_ok = d->st_ok;
             a.out_iters = d->st_iters;
             if ((rc = launch_decode(d, a, d->stream))) return rc;
+            const int slot = d->last_slot;   // this launch's own event pair (d->mu is held)
             HIP_OK(classify_launch(d->mc_y, d->st_bits, d->st_ok, d->st_iters, fc, n, nwords, cfg->first_frame + f0,
                                    cfg->codewords ? d->cw_dev : nullptr, cfg->codewords ? cfg->n_codewords : 1,
                                    d->counters, csr_row, csr_col, d->c.m, d->stream));
             HIP_OK(hipStreamSynchronize(d->stream));
             float ms = 0;
-            if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) kms += ms;
+            if (hipEventElapsedTime(&ms, d->ring_ev0[slot], d->ring_ev[slot]) == hipSuccess) kms += ms;
         }
         unsigned long long h[MC_NCOUNTERS];
         HIP_OK(hipMemcpy(h, d->counters, sizeof(h), hipMemcpyDeviceToHost));
@@ -1274,6 +1394,7 @@ int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc
         a.n_cw = cfg->codewords ? cfg->n_codewords : 1;
         a.counters = d->counters;
         if ((rc = launch_decode(d, a, d->stream))) return rc;
+        const int slot = d->last_slot;   // this launch's own event pair (d->mu is held)
         unsigned long long h[MC_NCOUNTERS];
         HIP_OK(hipMemcpyAsync(h, d->counters, sizeof(h), hipMemcpyDeviceToHost, d->stream));
         HIP_OK(hipStreamSynchronize(d->stream));
@@ -1285,13 +1406,17 @@ int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc
         res->sum_hamming_wrong = (int64_t) h[MC_HAM_WRONG];
         res->sum_iters = (int64_t) h[MC_ITERS];
         float ms = 0;
-        if (cfg->frames > 0 && hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) res->kernel_ms = ms;
+        if (cfg->frames > 0 && slot >= 0 && hipEventElapsedTime(&ms, d->ring_ev0[slot], d->ring_ev[slot]) == hipSuccess) res->kernel_ms = ms;
     }
     res->time_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
 
-int acg_ldpc_awgn_dev(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, float *y_dev, void *stream) {
+int acg_ldpc_mc_run(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, acg_ldpc_mc_result *res) {
+    return guarded([&] { return acg_ldpc_mc_run_impl(d, cfg, res); });
+}
+
+static int acg_ldpc_awgn_dev_impl(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, float *y_dev, void *stream) {
     if (!d || !cfg || !y_dev) {
         set_error("null argument");
         return 1;
@@ -1306,8 +1431,12 @@ int acg_ldpc_awgn_dev(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, float *y_
     return 0;
 }
 
+int acg_ldpc_awgn_dev(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg, float *y_dev, void *stream) {
+    return guarded([&] { return acg_ldpc_awgn_dev_impl(d, cfg, y_dev, stream); });
+}
+
 // ---------------------------------------------------------------- host generators
-int acg_ldpc_gen_codewords(const uint8_t *G, int32_t k, int32_t n, uint32_t seed, int64_t count, uint8_t *out) {
+static int acg_ldpc_gen_codewords_impl(const uint8_t *G, int32_t k, int32_t n, uint32_t seed, int64_t count, uint8_t *out) {
     if (!G || !out || k <= 0 || n <= 0 || count < 0) {
         set_error("bad argument");
         return 1;
@@ -1325,9 +1454,13 @@ int acg_ldpc_gen_codewords(const uint8_t *G, int32_t k, int32_t n, uint32_t seed
     return 0;
 }
 
+int acg_ldpc_gen_codewords(const uint8_t *G, int32_t k, int32_t n, uint32_t seed, int64_t count, uint8_t *out) {
+    return guarded([&] { return acg_ldpc_gen_codewords_impl(G, k, n, seed, count, out); });
+}
+
 double acg_ldpc_llr_variance(double snr) { return std::pow(10, -(snr / 10)) / 2; }
 
-int acg_ldpc_transmit_host(const uint8_t *codewords, int64_t n_codewords, int32_t n, int64_t first_frame,
+static int acg_ldpc_transmit_host_impl(const uint8_t *codewords, int64_t n_codewords, int32_t n, int64_t first_frame,
                            int64_t frames, double snr, double *y) {
     if (!y || n <= 0 || frames < 0 || (codewords && n_codewords <= 0)) {
         set_error("bad argument");
@@ -1344,8 +1477,13 @@ int acg_ldpc_transmit_host(const uint8_t *codewords, int64_t n_codewords, int32_
     return 0;
 }
 
+int acg_ldpc_transmit_host(const uint8_t *codewords, int64_t n_codewords, int32_t n, int64_t first_frame,
+                           int64_t frames, double snr, double *y) {
+    return guarded([&] { return acg_ldpc_transmit_host_impl(codewords, n_codewords, n, first_frame, frames, snr, y); });
+}
+
 // ---------------------------------------------------------------- debug helpers (tests only)
-int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t frames, double snr, int32_t iters,
+static int acg_ldpc_debug_bp_trace_impl(const acg_ldpc_code *code, const double *y, int32_t frames, double snr, int32_t iters,
                             int32_t f64, int32_t engine, int32_t lanes_per_frame, double *c2v, double *v2c_mag,
                             double *v2c_sgn, double *post) {
     if (!code || !y || frames < 1 || frames > 64 || iters < 1) {
@@ -1466,7 +1604,13 @@ int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t 
     return rc;
 }
 
-int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f64) {
+int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t frames, double snr, int32_t iters,
+                            int32_t f64, int32_t engine, int32_t lanes_per_frame, double *c2v, double *v2c_mag,
+                            double *v2c_sgn, double *post) {
+    return guarded([&] { return acg_ldpc_debug_bp_trace_impl(code, y, frames, snr, iters, f64, engine, lanes_per_frame, c2v, v2c_mag, v2c_sgn, post); });
+}
+
+static int acg_ldpc_debug_phi_impl(const void *x_host, void *out_host, int32_t n, int32_t f64) {
     const size_t es = f64 ? 8 : 4;
     void *dx = nullptr, *dout = nullptr;
     HIP_OK(hipMalloc(&dx, es * n));
@@ -1478,6 +1622,10 @@ int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f6
     (void) hipFree(dx);
     (void) hipFree(dout);
     return 0;
+}
+
+int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f64) {
+    return guarded([&] { return acg_ldpc_debug_phi_impl(x_host, out_host, n, f64); });
 }
 
 }  // extern "C"

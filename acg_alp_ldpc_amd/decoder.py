@@ -12,6 +12,7 @@
 
 Every call runs on the GPU through libacg_ldpc_hip.so; there is no CPU path.
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -24,15 +25,23 @@ from .code import ParityCheckMatrix
 class Decoder:
     _algo = None
 
+    # The reference hands H to every decode() (algo/algo.h:8) and its optimize_H loop hands a NEW H per proposal to one
+    # shared decoder (optimize_H.cpp:16-25,89-104): the analysed-graph cache is therefore bounded.  Least recently used
+    # handles beyond MAX_HANDLES are destroyed (device memory, streams and events go with them).
+    MAX_HANDLES = 8
+
     def __init__(self, max_iter, early_exit=True, precision=_lib.PREC_DEFAULT, device=-1, lanes_per_frame=0,
-                 engine=_lib.ENGINE_AUTO):
+                 engine=_lib.ENGINE_AUTO, schedule=_lib.SCHEDULE_FLOODING, fast_setup=False, max_handles=None):
         self.max_iter = int(max_iter)
         self.early_exit = bool(early_exit)
         self.precision = precision
         self.device = device
         self.lanes_per_frame = lanes_per_frame
         self.engine = engine
-        self._handles = {}  # analysed-graph cache keyed on H (SURVEY §8b "Inputs")
+        self.schedule = schedule
+        self.fast_setup = bool(fast_setup)
+        self.max_handles = int(max_handles) if max_handles else self.MAX_HANDLES
+        self._handles = collections.OrderedDict()  # analysed-graph cache keyed on H (SURVEY §8b "Inputs"), LRU order
 
     # -- parameters -------------------------------------------------------------------------
     def _params(self):
@@ -45,31 +54,46 @@ class Decoder:
         p.device = self.device
         p.lanes_per_frame = self.lanes_per_frame
         p.engine = self.engine
+        p.schedule = self.schedule
+        p.fast_setup = 1 if self.fast_setup else 0
         return p
 
     # -- handle cache -----------------------------------------------------------------------
     def _key(self, H):
+        """ParityCheckMatrix objects are keyed on identity (they are immutable); dense arrays on their CONTENT: shape + the
+        packed bits themselves (5.6 KB for 160 x 280), compared for equality by the dict — a hash alone could collide and
+        silently decode against the wrong graph."""
         if isinstance(H, ParityCheckMatrix):
             return ("pcm", id(H))
-        a = np.ascontiguousarray(H, dtype=np.uint8)
-        return ("dense", a.shape, hash(a.tobytes()))
+        a = np.ascontiguousarray(H)
+        if a.ndim != 2:
+            raise ValueError("H must be an m x n matrix")
+        return ("dense", a.shape, np.packbits(a != 0).tobytes())
 
     def handle(self, H):
         k = self._key(H)
         ent = self._handles.get(k)
-        if ent is None:
-            code = H if isinstance(H, ParityCheckMatrix) else ParityCheckMatrix(H)
-            h = C.c_void_p()
-            p = self._params()
-            check(lib().acg_ldpc_decoder_create(code._h, C.byref(p), C.byref(h)))
-            ent = (h, code)
-            self._handles[k] = ent
+        if ent is not None:
+            self._handles.move_to_end(k)
+            return ent
+        code = H if isinstance(H, ParityCheckMatrix) else ParityCheckMatrix(H)
+        h = C.c_void_p()
+        p = self._params()
+        check(lib().acg_ldpc_decoder_create(code._h, C.byref(p), C.byref(h)))
+        ent = (h, code)
+        self._handles[k] = ent
+        while len(self._handles) > self.max_handles:
+            _, (old, _) = self._handles.popitem(last=False)
+            lib().acg_ldpc_decoder_destroy(old)   # synchronises the handle's stream first
         return ent
+
+    def live_handles(self):
+        return len(self._handles)
 
     def close(self):
         for h, _ in self._handles.values():
             lib().acg_ldpc_decoder_destroy(h)
-        self._handles = {}
+        self._handles = collections.OrderedDict()
 
     def __del__(self):
         try:
@@ -122,6 +146,13 @@ class Decoder:
         h, _ = self.handle(H)
         return float(lib().acg_ldpc_decoder_last_kernel_ms(h))
 
+    def describe(self, H):
+        """one line naming the engine / kernel instance / launch shape of the handle for H"""
+        h, _ = self.handle(H)
+        buf = C.create_string_buffer(1024)
+        lib().acg_ldpc_decoder_describe(h, buf, 1024)
+        return buf.value.decode()
+
     def layout(self, H):
         h, _ = self.handle(H)
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -139,7 +170,8 @@ class BeliefPropagationDecoder(Decoder):
 
 
 class MinSumDecoder(Decoder):
-    """Build-added normalised min-sum (north_star).  Not in the reference: parity unpinned."""
+    """Build-added normalised min-sum (north_star).  Not in the reference: parity unpinned.
+    schedule=SCHEDULE_LAYERED: layered (row-block sequential) schedule — about half the sweeps for the same FER."""
     _algo = _lib.ALGO_MINSUM
 
     def __init__(self, max_iter, scale=1.0, **kw):

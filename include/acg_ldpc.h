@@ -57,6 +57,16 @@ enum {
     ACG_LDPC_ENGINE_STREAMED = 2  /* messages [edge][frame] in HBM, one lane per frame, coalesced sweeps (any code size) */
 };
 
+/* BP message schedule */
+enum {
+    ACG_LDPC_SCHEDULE_FLOODING = 0, /* the reference's schedule (bp.h:183-199): all checks, then all variables */
+    ACG_LDPC_SCHEDULE_LAYERED = 1   /* build-added, min-sum only: the block rows of a quasi-cyclic H (or, for any
+                                       other H, groups of checks that share no variable) are processed in sequence and the
+                                       posteriors are updated in place after every layer, so one sweep does the work of about
+                                       two flooding sweeps.  A DIFFERENT algorithm from the reference's: parity is FER-level
+                                       only (and min-sum itself is unpinned). Sum-product refuses it. */
+};
+
 /* noise source for acg_ldpc_mc_run */
 enum {
     ACG_LDPC_NOISE_DEVICE_PHILOX = 0, /* counter-based, keyed on (seed, global frame, symbol): same
@@ -84,6 +94,7 @@ typedef struct acg_ldpc_params {
                            (bank-conflict search; cached per parity-check matrix inside the process);
                            1 = skip that search (throw-away decoders, e.g. one per proposal of the check-matrix local
                            search, optimize_H.cpp:89-104).  Results are identical either way. */
+    int32_t schedule;   /* ACG_LDPC_SCHEDULE_* (BP only; default flooding) */
 } acg_ldpc_params;
 
 void acg_ldpc_params_default(acg_ldpc_params *p);
@@ -134,8 +145,9 @@ const char *acg_ldpc_decoder_name(const acg_ldpc_decoder *dec);
  *   ok     host, frames bytes: the reference's bool (BP: zero syndrome reached; QP-ADMM: always 1 unless the
  *          e_min*mu<=alpha guard fires, qp_admm.h:112-114,177)
  *   iters  host, frames int32 or NULL: sweeps executed until exit (BP: iteration of the first zero syndrome)
- * Large batches are pipelined in chunks of 65536 frames through two pinned staging sets (host threads copy / unpack
- * while the GPU decodes the previous chunk); the rate is PCIe-bound: 8 bytes in + 1 byte out per symbol. */
+ * Large batches are pipelined in chunks of at most 65536 frames / 256 MiB of symbols through two pinned staging sets
+ * (a process-wide pool of host threads, created on the first batch of >= 4096 frames, copies / unpacks while the GPU
+ * decodes the previous chunk); the rate is PCIe-bound: 8 bytes in + 1 byte out per symbol. */
 int acg_ldpc_decode_batch(acg_ldpc_decoder *dec, const double *y, int64_t frames, double snr, uint8_t *bits,
                           uint8_t *ok, int32_t *iters);
 
@@ -155,12 +167,17 @@ int acg_ldpc_decode_batch_dev(acg_ldpc_decoder *dec, const void *y_dev, int32_t 
                               double snr, uint32_t *bits_dev, uint8_t *ok_dev, int32_t *iters_dev, void *stream);
 /* block until the decoder's own stream is idle */
 int acg_ldpc_decoder_sync(acg_ldpc_decoder *dec);
-/* duration in ms of the most recent decode/mc kernel launch on this handle, measured with HIP
- * events recorded on the launch stream (synchronises on the stop event) */
+/* duration in ms of the most recent decode/mc kernel launch on this handle, measured with the HIP event pair that
+ * launch recorded on its own stream (every launch owns a pair: launches of one handle overlapping on two streams never
+ * pair each other's events); synchronises on the stop event */
 float acg_ldpc_decoder_last_kernel_ms(acg_ldpc_decoder *dec);
 /* bytes of LDS per frame, frames resident per CU, lanes per frame chosen for this code (diagnostics) */
 void acg_ldpc_decoder_layout(const acg_ldpc_decoder *dec, int32_t *lds_bytes_per_frame, int32_t *lanes_per_frame,
                              int32_t *frames_per_block, int32_t *grid_blocks);
+
+/* one line naming the engine / kernel instance / launch shape this handle uses (diagnostics; bench.py records it with every
+ * timed leg).  Writes at most cap bytes incl. the terminating 0; returns the size the full text needs. */
+int32_t acg_ldpc_decoder_describe(const acg_ldpc_decoder *dec, char *buf, int32_t cap);
 
 /* ---- Monte-Carlo loop (experiment.h) --------------------------------------------------- */
 

@@ -34,7 +34,7 @@ def test_exports_every_declared_symbol(A):
 def test_abi_struct_sizes(A):
     from acg_alp_ldpc_amd import _lib
     # must match the C layout in include/acg_ldpc.h (x86-64 SysV)
-    assert C.sizeof(_lib.Params) == 64
+    assert C.sizeof(_lib.Params) == 72   # 2 + 4 doubles + 7 int32 (incl. schedule), padded to 8
     assert C.sizeof(_lib.McCfg) == 56
     assert C.sizeof(_lib.McResult) == 72
     p = _lib.Params()
