@@ -53,6 +53,15 @@ class ParityCheckMatrix:
         check(rc)
         return G, True
 
+    def layers(self):
+        """layers of the layered min-sum schedule (SCHEDULE_LAYERED): (lanes per frame G, circulant size Z or 0,
+        [n_layers, G] check ids in processing order, -1 = empty lane)"""
+        G, nl, Z = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().acg_ldpc_debug_layers(self._h, C.byref(G), C.byref(nl), C.byref(Z), None, 0))
+        chk = np.full((nl.value, G.value), -1, dtype=np.int32)
+        check(lib().acg_ldpc_debug_layers(self._h, C.byref(G), C.byref(nl), C.byref(Z), chk.ctypes.data, chk.size))
+        return G.value, Z.value, chk
+
     def is_codeword(self, bits):
         b = np.ascontiguousarray(bits, dtype=np.uint8)
         assert b.shape[-1] == self.n

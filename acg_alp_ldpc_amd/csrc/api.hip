@@ -38,6 +38,8 @@ const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, 
 const void *bp_kernel_ptr_dbg(int f64, int L);
 const void *bp_block_kernel_ptr_dbg(int f64);
 const void *bp_pair_kernel_ptr(int L, bool regular);
+const void *bp_layered_kernel_ptr(int G, int waves);
+hipError_t bp_layered_launch(const void *kernel, const LayerTables &t, const DecodeArgs &a, int grid, int block, size_t lds, hipStream_t s);
 const void *bp_streamed_ptr(int algo, int f64);
 const void *bp_streamed_ring_ptr(int algo, bool nt);
 hipError_t bp_streamed_ring_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid, hipStream_t s);
@@ -220,6 +222,10 @@ struct acg_ldpc_decoder {
     int variant = -1;       // wave-group kernels: 0 / 1 / 2 (see bp_inst_*.hip); -1 = workgroup-per-frame
     bool pair = false;      // ACG_LDPC_PREC_F16: two frames per workgroup, packed half-precision messages (bp_pair.hip)
     bool blk_idxlds = false, blk_idxreg = false;
+    // layered min-sum (bp_layered.hip)
+    bool layered = false;
+    LayeredLayout llay;
+    LayerTables ltab{};
     // streamed BP engine
     bool streamed = false;
     StreamTables stab{};
@@ -495,8 +501,100 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
     return 0;
 }
 
+// schedule = LAYERED: min-sum over conflict-free layers of checks with in-place posteriors (bp_layered.hip)
+static int decoder_setup_layered(acg_ldpc_decoder *d) {
+    const Code &c = d->c;
+    if (d->p.algo != ACG_LDPC_BP_MINSUM) {
+        set_error("ACG_LDPC_SCHEDULE_LAYERED exists for the min-sum decoder only: the reference's sum-product BP floods (bp.h:183-199) "
+                  "and a layered schedule is a different algorithm (FER-level parity at best)");
+        return 3;
+    }
+    if (d->p.engine == ACG_LDPC_ENGINE_STREAMED || (d->p.precision != ACG_LDPC_PREC_DEFAULT && d->p.precision != ACG_LDPC_PREC_F32)) {
+        set_error("the layered schedule runs on the LDS-resident engine in fp32 only");
+        return 3;
+    }
+    if (!bp_layered_build(c, d->llay)) return 3;
+    const LayeredLayout &ll = d->llay;
+    if (d->p.lanes_per_frame != 0 && d->p.lanes_per_frame != ll.G) {
+        set_error("layered schedule: lanes_per_frame is chosen by the layering (pass 0)");
+        return 3;
+    }
+    LayerTables &t = d->ltab;
+    int32_t *p32 = nullptr;
+    uint16_t *p16 = nullptr;
+    if (upload<int32_t>(ll.layer, &p32)) return 10;
+    d->dev_allocs.push_back(p32);
+    t.layer = p32;
+    if (ll.qc) {
+        if (upload<int32_t>(ll.proto, &p32)) return 10;
+        d->dev_allocs.push_back(p32);
+        t.proto = p32;
+        t.pos = nullptr;
+    } else {
+        if (upload<uint16_t>(ll.pos, &p16)) return 10;
+        d->dev_allocs.push_back(p16);
+        t.pos = p16;
+        t.proto = nullptr;
+    }
+    t.n_layers = ll.n_layers;
+    t.Z = ll.Z;
+    t.n = c.n;
+    t.nwords = (c.n + 31) / 32;
+    t.e_pad = ll.e_pad;
+    t.p_words = (c.n + 1 + 3) & ~3;
+    t.tab_lds_bytes = (int) (((size_t) ll.e_pad * 2 + 15) & ~(size_t) 15);
+    // frame stride = G (mod 32) words: the lanes of the frames sharing a wavefront then fall into disjoint LDS banks
+    int words = t.p_words + t.e_pad + t.nwords;
+    while (words % 32 != ll.G % 32) words++;
+    t.lds_bytes_per_frame = words * 4;
+    const int fpw = 64 / ll.G;
+    const size_t per_wave = (size_t) t.lds_bytes_per_frame * fpw;
+    // wavefronts per workgroup: the one that wastes the least LDS on the shared table while leaving >= 2 workgroups per CU
+    int waves = 4;
+    while (waves > 1 && (per_wave * waves + t.tab_lds_bytes) * 2 > 160 * 1024) waves >>= 1;
+    {   // prefer the workgroup size that fits the most wavefronts per CU
+        int best_w = waves, best_n = 0;
+        for (int w : {4, 2, 1}) {
+            const size_t blk = per_wave * w + t.tab_lds_bytes;
+            if (blk > 160 * 1024) continue;
+            const int nw = (int) ((160 * 1024) / blk) * w;
+            if (nw > best_n) { best_n = nw; best_w = w; }
+        }
+        waves = best_w;
+    }
+    if (per_wave * waves + t.tab_lds_bytes > 160 * 1024) {
+        set_error("layered schedule: a frame (posteriors + messages) does not fit in LDS");
+        return 3;
+    }
+    d->layered = true;
+    d->L = ll.G;
+    d->f64 = 0;
+    d->block = waves * 64;
+    d->frames_per_block = waves * fpw;
+    d->lds_block = per_wave * waves + t.tab_lds_bytes;
+    const void *kp = bp_layered_kernel_ptr(ll.G, waves);
+    if (!kp) {
+        set_error("no layered kernel instance for this group width");
+        return 3;
+    }
+    if (d->lds_block > 64 * 1024) HIP_OK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block));
+    int occ = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, d->block, d->lds_block));
+    if (occ < 1) occ = 1;
+    d->kernel[0] = kp;
+    d->kernel[1] = nullptr;   // Monte-Carlo runs go AWGN kernel -> decode -> classification kernel
+    d->grid_cap[0] = d->grid_cap[1] = occ * d->cu_count;
+    d->tab.lds_bytes_per_frame = t.lds_bytes_per_frame;
+    return 0;
+}
+
 static int decoder_setup_bp(acg_ldpc_decoder *d) {
     const Code &c = d->c;
+    if (d->p.schedule == ACG_LDPC_SCHEDULE_LAYERED) return decoder_setup_layered(d);
+    if (d->p.schedule != ACG_LDPC_SCHEDULE_FLOODING) {
+        set_error("unknown schedule");
+        return 1;
+    }
     if (d->p.engine != ACG_LDPC_ENGINE_AUTO && d->p.engine != ACG_LDPC_ENGINE_FUSED &&
         d->p.engine != ACG_LDPC_ENGINE_STREAMED) {
         set_error("unknown engine");
@@ -852,13 +950,14 @@ static std::string describe(const acg_ldpc_decoder *d) {
         snprintf(b, sizeof b, "%s engine=lds lanes_per_frame=%d frames_per_block=%d lds_bytes_per_frame=%d grid_cap=%d", algo, L, fpb, lds, grid);
     } else if (d->streamed) {
         const size_t slab = (size_t) d->stab.ws_words_per_wave * 4;
-        snprintf(b, sizeof b, "%s engine=streamed kernel=%s%s f64=%d slab_bytes=%zu slabs=%d workspace_bytes=%zu workgroups_per_cu=%d schedule=%s",
+        snprintf(b, sizeof b, "%s engine=streamed kernel=%s%s f64=%d slab_bytes=%zu slabs=%d workspace_bytes=%zu workspace_base=%p "
+                               "workgroups_per_cu=%d schedule=%s",
                  algo, d->sring ? "bp_streamed_ring_kernel" : "bp_streamed_kernel", d->sring ? (d->sring_nt ? "<NT>" : "<default-policy>") : "",
-                 d->f64, slab, d->sgrid, slab * (size_t) d->sgrid, d->sring ? d->sring_per_cu : 2, "flooding");
+                 d->f64, slab, d->sgrid, slab * (size_t) d->sgrid, (void *) d->sws, d->sring ? d->sring_per_cu : 2, "flooding");
     } else {
         snprintf(b, sizeof b, "%s engine=fused kernel=%s lanes_per_frame=%d f64=%d block=%d frames_per_block=%d lds_block=%zu grid_cap=%d "
                                "idx_lds=%d idx_reg=%d schedule=%s",
-                 algo, d->pair ? "bp_pair_kernel" : (d->variant < 0 ? "bp_block_kernel" : "bp_fused_kernel"), d->L, d->f64, d->block,
+                 algo, d->layered ? "bp_layered_kernel" : (d->pair ? "bp_pair_kernel" : (d->variant < 0 ? "bp_block_kernel" : "bp_fused_kernel")), d->L, d->f64, d->block,
                  d->frames_per_block, d->lds_block, d->grid_cap[0], d->variant < 0 ? (int) d->blk_idxlds : (d->variant > 0), (int) d->blk_idxreg,
                  d->p.schedule == ACG_LDPC_SCHEDULE_LAYERED ? "layered" : "flooding");
     }
@@ -926,6 +1025,14 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         } else {
             HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
         }
+    } else if (d->layered) {
+        if (a.mc) {
+            set_error("internal: the layered kernel has no in-kernel generator");
+            return 11;
+        }
+        const int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
+        const int grid = (int) std::min<int64_t>(blocks, d->grid_cap[0]);
+        HIP_OK(bp_layered_launch(d->kernel[0], d->ltab, a, grid, d->block, d->lds_block, s));
     } else {
         int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
         const int mc = a.mc ? 1 : 0;
@@ -1327,7 +1434,7 @@ static int acg_ldpc_mc_run_impl(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg,
     int rc = 0;
     if (cfg->noise == ACG_LDPC_NOISE_HOST_MT19937) {
         rc = mc_run_host_noise(d, cfg, res);
-    } else if (d->streamed || d->pair || (d->admm && admm_device_unfused_mc(d->admm, nullptr, nullptr))) {
+    } else if (d->streamed || d->pair || d->layered || (d->admm && admm_device_unfused_mc(d->admm, nullptr, nullptr))) {
         // AWGN kernel -> decode -> classify kernel, in bounded chunks, all on the device.  Used by the streamed BP
         // engine (no in-kernel generator) and by the workgroup-per-frame QP-ADMM kernel, whose fused Monte-Carlo
         // variant needs 156 VGPRs (3 waves/SIMD) against 117 (4) for the plain decode: 1.6 M vs 2.7 M frames/s.
@@ -1608,6 +1715,23 @@ int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t 
                             int32_t f64, int32_t engine, int32_t lanes_per_frame, double *c2v, double *v2c_mag,
                             double *v2c_sgn, double *post) {
     return guarded([&] { return acg_ldpc_debug_bp_trace_impl(code, y, frames, snr, iters, f64, engine, lanes_per_frame, c2v, v2c_mag, v2c_sgn, post); });
+}
+
+int acg_ldpc_debug_layers(const acg_ldpc_code *code, int32_t *lanes, int32_t *n_layers, int32_t *qc_Z, int32_t *chk, int64_t cap) {
+    return guarded([&]() -> int {
+        if (!code) {
+            set_error("null argument");
+            return 1;
+        }
+        LayeredLayout ll;
+        if (!bp_layered_build(code->c, ll)) return 3;
+        if (lanes) *lanes = ll.G;
+        if (n_layers) *n_layers = ll.n_layers;
+        if (qc_Z) *qc_Z = ll.qc ? ll.Z : 0;
+        if (chk)
+            for (int64_t i = 0; i < std::min<int64_t>(cap, (int64_t) ll.chk.size()); i++) chk[i] = ll.chk[(size_t) i];
+        return 0;
+    });
 }
 
 static int acg_ldpc_debug_phi_impl(const void *x_host, void *out_host, int32_t n, int32_t f64) {

@@ -1,0 +1,301 @@
+// Layered (row-block sequential) normalised min-sum for gfx950 — SURVEY §8(f) N4, BP side.
+//
+// NOT the reference's schedule: algo/bp.h:183-199 floods (all checks, then all variables).  Here the checks are cut into
+// LAYERS — sets of checks of one degree that share no variable; for the quasi-cyclic matrices of the reference (H05 /
+// optimalH: 8 x 14 arrays of 20 x 20 cyclic-shift blocks, optimize_H.cpp:27-63) the layers are the 8 block rows — and the
+// posteriors are updated in place after every layer, so the second layer already sees what the first one learnt.  One
+// sweep over all layers does the work of about two flooding sweeps; parity with the reference is FER-level only (and
+// min-sum itself is build-added, SURVEY D2: parity unpinned).
+//
+// Mapping.  G lanes of a wavefront (G = 16, 20, 32 or 64; H05: G = Z = 20, three frames per wavefront) own one frame; lane l
+// handles check l of the current layer.  Per frame LDS holds the posteriors P[v] (natural variable order) and the
+// check-to-variable messages R[layer][edge j][lane] — the latter are only ever touched by the lane that owns the check, at
+// immediate offsets from one per-layer address, so they need no index at all.  Which posterior cell edge j of check (layer,
+// lane) reads comes from a 16-bit byte-offset table shared by the workgroup; for a quasi-cyclic H that table is never stored
+// in memory: the kernel builds it when it starts from the (block column, shift) list of the block rows —
+// variable = C_j * Z + (k + s_j) mod Z, optimize_H.cpp:41 — which is all the graph description this engine is given.
+//
+// One layer step, per lane (degree D compile time, dispatched wave-uniformly):
+//     pos_j <- table;  P_j <- LDS;  R_j <- LDS           (3 D LDS reads)
+//     Q_j = P_j - R_j;   two smallest |Q_j| by v_med3 / v_min;   sign product by XOR
+//     R'_j = scale * (|Q_j| == min1 ? min2 : min1) with sign;   P'_j = Q_j + R'_j       (2 D LDS writes)
+// Stopping rule (exact, no separate syndrome pass): a layer step is QUIET when every check of the layer is satisfied by the
+// signs of the posteriors it READ and none of the posteriors it WROTE changed sign.  An iteration (one round over all layers)
+// in which every step was quiet has left the hard decisions untouched and has seen them satisfy every check: H x = 0, the
+// frame stops there (early exit) or its output is latched (fixed work).  A frame that runs out of iterations without a quiet
+// round gets one explicit syndrome pass over its final posteriors.  Results are deterministic: every frame starts at layer 0.
+// Frames are handed out dynamically as in the flooding kernel (bp_core.inc), at round boundaries.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels.hpp"
+
+namespace acg {
+
+typedef const int32_t __attribute__((address_space(4))) *lsconst_i32;
+__device__ __forceinline__ int lsload(const int32_t *p, int i) { return ((lsconst_i32) (p))[i]; }
+
+__device__ __forceinline__ void lwave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one layer step of degree D for this lane's check.  Pb: the frame's posteriors (byte-addressed), Rl / Tl: this lane's column
+// of the layer's messages / position table.  store: the lane owns a check of an active frame.
+// -> sign bit set <=> the step was not quiet for this lane
+template <int D, int G>
+__device__ __forceinline__ uint32_t layer_step(unsigned char *__restrict__ Pb, float *__restrict__ Rl, const uint16_t *__restrict__ Tl,
+                                               const bool store, const float scale) {
+    int pos[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) pos[j] = Tl[j * G];
+    float p[D], q[D], a[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) p[j] = *reinterpret_cast<const float *>(Pb + pos[j]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] = p[j] - Rl[j * G];
+    uint32_t S = 0, noisy = 0;
+    float m1 = INFINITY, m2 = INFINITY;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        noisy ^= __float_as_uint(p[j]);                     // parity of the hard decisions this check sees
+        S ^= __float_as_uint(q[j]);
+        a[j] = __uint_as_float(__float_as_uint(q[j]) & 0x7FFFFFFFu);
+        m2 = __builtin_amdgcn_fmed3f(a[j], m1, m2);
+        m1 = __builtin_fminf(m1, a[j]);
+    }
+    const float m1s = scale * m1, m2s = scale * m2;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const float mag = (a[j] == m1) ? m2s : m1s;         // a tie makes m2 == m1: either answer is the same
+        const float rn = __uint_as_float((__float_as_uint(mag) & 0x7FFFFFFFu) | ((S ^ __float_as_uint(q[j])) & 0x80000000u));
+        const float pn = q[j] + rn;
+        noisy |= __float_as_uint(pn) ^ __float_as_uint(p[j]);   // a hard decision flipped
+        if (store) {
+            *reinterpret_cast<float *>(Pb + pos[j]) = pn;
+            Rl[j * G] = rn;
+        }
+    }
+    return noisy;
+}
+
+// parity of the posteriors' signs over this lane's check of a layer (explicit syndrome pass)
+template <int D, int G>
+__device__ __forceinline__ uint32_t layer_parity(const unsigned char *__restrict__ Pb, const uint16_t *__restrict__ Tl) {
+    uint32_t S = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) S ^= __float_as_uint(*reinterpret_cast<const float *>(Pb + Tl[j * G]));
+    return S;
+}
+
+#define ACG_LAYER_SWITCH(md, CALL) \
+    switch (md) {                  \
+        case 1: CALL(1); break;    \
+        case 2: CALL(2); break;    \
+        case 3: CALL(3); break;    \
+        case 4: CALL(4); break;    \
+        case 5: CALL(5); break;    \
+        case 6: CALL(6); break;    \
+        case 7: CALL(7); break;    \
+        case 8: CALL(8); break;    \
+        default: break;            \
+    }
+
+template <int G>
+__device__ __forceinline__ bool lgroup_any(bool pred, int g) {
+    const unsigned long long b = __ballot(pred);
+    if (G == 64) return b != 0ull;
+    const unsigned long long mask = ((1ull << (G & 63)) - 1ull) << (g * G);
+    return (b & mask) != 0ull;
+}
+
+template <int G, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTables t, const DecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int FPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / G;                 // (lanes beyond FPW * G idle: 60..63 for G = 20)
+    const int l = lane - g * G;
+    const bool lane_used = g < FPW;
+
+    // ---- position table of the workgroup: byte offset of the posterior cell of (layer, edge, lane) ----------------------------
+    uint16_t *TAB = reinterpret_cast<uint16_t *>(smem);
+    if (t.proto) {
+        // quasi-cyclic H: edge addressing is arithmetic, evaluated once per workgroup
+        for (int b = 0; b < t.n_layers; ++b) {
+            const int deg = lsload(t.layer, 4 * b), off = lsload(t.layer, 4 * b + 1), cnt = lsload(t.layer, 4 * b + 2);
+            const int w3 = lsload(t.layer, 4 * b + 3), p0 = w3 & 0xFFFF, row0 = w3 >> 16;
+            for (int i = threadIdx.x; i < deg * G; i += blockDim.x) {
+                const int j = i / G, k = i - j * G;
+                int v = t.n;                                                           // the neutral cell
+                if (k < cnt) {
+                    const int C = t.proto[2 * (p0 + j)], s = t.proto[2 * (p0 + j) + 1];
+                    v = C * t.Z + (row0 + k + s) % t.Z;                                // optimize_H.cpp:41
+                }
+                TAB[off + i] = (uint16_t) (4 * v);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < t.e_pad; i += blockDim.x) TAB[i] = (uint16_t) (4 * t.pos[i]);
+    }
+    __syncthreads();
+
+    const int grp_in_block = wave * FPW + (lane_used ? g : 0);
+    unsigned char *base = smem + t.tab_lds_bytes + (size_t) grp_in_block * t.lds_bytes_per_frame;
+    unsigned char *Pb = base;                                             // P[n] + neutral cell (+ padding)
+    float *P = reinterpret_cast<float *>(base);
+    float *R = P + t.p_words;
+    uint32_t *OB = reinterpret_cast<uint32_t *>(R + t.e_pad);
+    const float scale = a.ms_scale;
+    const int NL = t.n_layers;
+
+    constexpr int CHUNK = 4 * FPW;
+    int64_t wnext = 0, wend = 0;
+    int64_t frame = 0;
+    bool active = false, want = lane_used, need_init = false, latched = false;
+    int it = 0;             // iterations (rounds over all layers) this frame has been through
+    uint32_t noisy_acc = 0; // sign bit: some step of the current round was not quiet for this lane's checks
+
+    auto emit = [&](const bool out_now, const bool fail_now) {
+        if (__ballot(out_now || fail_now) != 0ull) {
+            if (out_now || fail_now)
+                for (int w = l; w < t.nwords; w += G) OB[w] = 0u;
+            lwave_sync();
+            if (out_now)
+                for (int v = l; v < t.n; v += G)
+                    if (__float_as_uint(P[v]) >> 31) atomicOr(&OB[v >> 5], 1u << (v & 31));
+            lwave_sync();
+            if (out_now || fail_now) {
+                if (a.out_bits)
+                    for (int w = l; w < t.nwords; w += G) a.out_bits[(size_t) frame * t.nwords + w] = OB[w];
+                if (l == 0) {
+                    if (a.out_ok) a.out_ok[frame] = out_now ? 1 : 0;
+                    if (a.out_iters) a.out_iters[frame] = std::min(it, a.max_iter);
+                }
+                latched = true;
+            }
+        }
+    };
+    // explicit syndrome of the posteriors' signs (frames that ran out of iterations without a quiet round)
+    auto syndrome_bad = [&]() -> bool {
+        uint32_t acc = 0;
+        for (int bb = 0; bb < NL; ++bb) {
+            const int deg = lsload(t.layer, 4 * bb), off = lsload(t.layer, 4 * bb + 1), cnt = lsload(t.layer, 4 * bb + 2);
+            const uint16_t *Tl = TAB + off + l;
+            uint32_t S = 0;
+#define ACG_CALL(D) S = layer_parity<D, G>(Pb, Tl)
+            ACG_LAYER_SWITCH(deg, ACG_CALL)
+#undef ACG_CALL
+            acc |= (l < cnt) ? S : 0u;
+        }
+        return lgroup_any<G>((acc >> 31) != 0u, g);
+    };
+
+    for (;;) {
+        // ---- round boundary: frames that are done -------------------------------------------------------------------------
+        const bool loud = lgroup_any<G>((noisy_acc >> 31) != 0u, g);
+        noisy_acc = 0;
+        const bool conv = active && it > 0 && !loud;
+        const bool out_of_sweeps = active && it >= a.max_iter;
+        bool conv2 = conv;
+        if (__ballot(out_of_sweeps && !conv && !latched) != 0ull) {
+            const bool bad = syndrome_bad();            // wave-uniform control flow; the result is per group
+            if (out_of_sweeps && !conv && !latched && !bad && a.max_iter > 0) conv2 = true;
+        }
+        const bool out_now = conv2 && !latched;
+        const bool finish = active && ((a.early_exit && conv2) || out_of_sweeps);
+        const bool fail_now = finish && !conv2 && !latched;
+        emit(out_now, fail_now);
+        if (finish) {
+            active = false;
+            want = lane_used;
+        }
+        // ---- deal new frames to the groups that want one ------------------------------------------------------------------
+        unsigned long long wm = __ballot(want && l == 0);
+        while (wm != 0ull) {
+            const int leader = __builtin_ctzll(wm);
+            wm &= wm - 1ull;
+            if (wnext >= wend) {
+                unsigned long long nb = 0;
+                if (lane == 0) nb = atomicAdd(a.work_counter, (unsigned long long) CHUNK);
+                const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t) nb);
+                const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t) (nb >> 32));
+                wnext = (int64_t) (((unsigned long long) bhi << 32) | blo);
+                wend = wnext + CHUNK < a.frames ? wnext + CHUNK : a.frames;
+            }
+            const bool got = wnext < wend;
+            const int64_t f = wnext;
+            if (got) wnext += 1;
+            if (lane_used && g == leader / G) {
+                frame = f;
+                active = got;
+                need_init = got;
+                want = false;
+            }
+        }
+        if (__ballot(active) == 0ull) break;
+        // ---- (re)start groups on a new frame: P = channel LLR (channel.h:14-16), R = 0 ------------------------------------
+        if (__ballot(need_init) != 0ull) {
+            lwave_sync();
+            if (need_init) {
+                for (int v = l; v < t.n; v += G) {
+                    float llr;
+                    if (a.y_is_f64) llr = (float) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + v] / a.var);
+                    else llr = (float) ((double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + v] * a.inv_var2);
+                    P[v] = llr;
+                }
+                for (int w = t.n + l; w < t.p_words; w += G) P[w] = INFINITY;   // neutral cell: never the minimum, sign +
+                for (int w = l; w < t.e_pad; w += G) R[w] = 0.0f;
+                it = 0;
+                latched = false;
+                need_init = false;
+            }
+            lwave_sync();
+        }
+        // ---- one iteration: every layer in turn, posteriors updated in place ------------------------------------------------
+        for (int b = 0; b < NL; ++b) {
+            const int deg = lsload(t.layer, 4 * b), off = lsload(t.layer, 4 * b + 1), cnt = lsload(t.layer, 4 * b + 2);
+            float *Rl = R + off + l;
+            const uint16_t *Tl = TAB + off + l;
+            const bool mine = active && l < cnt;
+            uint32_t noisy = 0;
+#define ACG_CALL(D) noisy = layer_step<D, G>(Pb, Rl, Tl, mine, scale)
+            ACG_LAYER_SWITCH(deg, ACG_CALL)
+#undef ACG_CALL
+            lwave_sync();
+            noisy_acc |= mine ? noisy : 0u;
+        }
+        it += active ? 1 : 0;
+    }
+}
+
+template <int G>
+static const void *layered_ptr_w(int waves) {
+    switch (waves) {
+        case 1: return (const void *) bp_layered_kernel<G, 1>;
+        case 2: return (const void *) bp_layered_kernel<G, 2>;
+        default: return (const void *) bp_layered_kernel<G, 4>;
+    }
+}
+
+const void *bp_layered_kernel_ptr(int G, int waves) {
+    switch (G) {
+        case 16: return layered_ptr_w<16>(waves);
+        case 20: return layered_ptr_w<20>(waves);
+        case 32: return layered_ptr_w<32>(waves);
+        case 64: return layered_ptr_w<64>(waves);
+        default: return nullptr;
+    }
+}
+
+hipError_t bp_layered_launch(const void *kernel, const LayerTables &t, const DecodeArgs &a, int grid, int block, size_t lds, hipStream_t s) {
+    LayerTables tt = t;
+    DecodeArgs aa = a;
+    void *args[2] = {&tt, &aa};
+    return hipLaunchKernel(kernel, dim3(grid), dim3(block), args, lds, s);
+}
+
+}  // namespace acg

@@ -560,6 +560,103 @@ bool code_detect_qc(const Code &c, QcInfo &q) {
 }
 
 // ---------------------------------------------------------------- QP-ADMM block-kernel placement
+// Layers of the layered min-sum schedule (see LayeredLayout).
+bool bp_layered_build(const Code &c, LayeredLayout &o) {
+    o = LayeredLayout();
+    if (c.m <= 0 || c.n <= 0 || c.n >= 16000) {
+        set_error("layered schedule: n must be below 16000 (16-bit byte offsets of the posterior cells)");
+        return false;
+    }
+    // conflict-free same-degree check sets, in processing order
+    struct Set { int deg; std::vector<int> chk; int R; int row0; };
+    std::vector<Set> sets;
+    QcInfo q;
+    const bool qc = code_detect_qc(c, q) && q.Z >= 2;
+    if (qc) {
+        for (int R = 0; R < q.mb; R++) {
+            Set s{c.row_ptr[R * q.Z + 1] - c.row_ptr[R * q.Z], {}, R, 0};
+            for (int k = 0; k < q.Z; k++) s.chk.push_back(R * q.Z + k);
+            if (s.deg > 0) sets.push_back(s);
+        }
+    } else {
+        // greedy colouring: a check joins the first set of its degree in which none of its variables occurs yet
+        std::vector<std::vector<uint8_t>> used;  // per set: variable occupied
+        for (int r = 0; r < c.m; r++) {
+            const int deg = c.row_ptr[r + 1] - c.row_ptr[r];
+            if (deg == 0) continue;
+            size_t k = 0;
+            for (; k < sets.size(); k++) {
+                if (sets[k].deg != deg || (int) sets[k].chk.size() >= 64) continue;
+                bool free_ = true;
+                for (int e = c.row_ptr[r]; e < c.row_ptr[r + 1] && free_; e++) free_ = !used[k][c.edge_var[e]];
+                if (free_) break;
+            }
+            if (k == sets.size()) {
+                sets.push_back(Set{deg, {}, -1, 0});
+                used.emplace_back((size_t) c.n, 0);
+            }
+            sets[k].chk.push_back(r);
+            for (int e = c.row_ptr[r]; e < c.row_ptr[r + 1]; e++) used[k][c.edge_var[e]] = 1;
+        }
+    }
+    int maxdeg = 0;
+    for (auto &s : sets) maxdeg = std::max(maxdeg, s.deg);
+    if (maxdeg > 8) {
+        set_error("layered schedule: check degree above 8 is not supported");
+        return false;
+    }
+    // group width: the candidate that needs the fewest wavefront-steps per frame (layers / frames per wavefront)
+    int bestG = 64;
+    double best = 1e30;
+    for (int G : {16, 20, 32, 64}) {
+        long layers = 0;
+        for (auto &s : sets) layers += ((long) s.chk.size() + G - 1) / G;
+        const double cost = (double) layers / (64 / G);
+        if (cost < best - 1e-9) {
+            best = cost;
+            bestG = G;
+        }
+    }
+    const int G = bestG;
+    o.G = G;
+    o.qc = qc;
+    o.Z = qc ? q.Z : 0;
+    int off = 0;
+    for (auto &s : sets) {
+        int proto0 = 0;
+        if (qc) {
+            proto0 = (int) o.proto.size() / 2;
+            for (int C = 0; C < q.nb; C++)
+                if (q.shift[(size_t) s.R * q.nb + C] >= 0) {
+                    o.proto.push_back(C);
+                    o.proto.push_back(q.shift[(size_t) s.R * q.nb + C]);
+                }
+        }
+        for (size_t i0 = 0; i0 < s.chk.size(); i0 += (size_t) G) {
+            const int cnt = (int) std::min<size_t>((size_t) G, s.chk.size() - i0);
+            o.layer.push_back(s.deg);
+            o.layer.push_back(off);
+            o.layer.push_back(cnt);
+            o.layer.push_back(proto0 | ((int) i0 << 16));  // QC: first proto entry | first row of the chunk inside its block row
+            for (int l = 0; l < G; l++) o.chk.push_back(l < cnt ? s.chk[i0 + l] : -1);
+            o.pos.resize((size_t) off + (size_t) s.deg * G, (uint16_t) c.n);
+            for (int l = 0; l < cnt; l++) {
+                const int r = s.chk[i0 + l];
+                for (int j = 0; j < s.deg; j++) o.pos[(size_t) off + (size_t) j * G + l] = (uint16_t) c.edge_var[c.row_ptr[r] + j];
+            }
+            off += s.deg * G;
+            o.n_layers++;
+        }
+    }
+    o.e_pad = off;
+    if (o.n_layers == 0) {
+        set_error("layered schedule: the matrix has no checks");
+        return false;
+    }
+    if (qc && q.Z >= (1 << 15)) o.qc = false;
+    return true;
+}
+
 namespace {
 
 int admm_llen(const AdmmLayout &A, int i) { return A.var_ptr[i + 1] - A.var_ptr[i]; }

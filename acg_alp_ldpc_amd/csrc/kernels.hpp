@@ -56,6 +56,18 @@ struct DecodeArgs {
     void *dbg_post;
 };
 
+// Layered min-sum (bp_layered.hip; LayeredLayout in ldpc_internal.hpp)
+struct LayerTables {
+    const int32_t *layer;    // [n_layers][4] = {degree, message offset (words), checks, first proto entry | first row << 16}
+    const int32_t *proto;    // quasi-cyclic H: {block column, shift} pairs per block row; null = use pos
+    const uint16_t *pos;     // any other H: [e_pad] variable of (layer, edge, lane), n = neutral cell; null when proto is set
+    int32_t n_layers, Z, n, nwords;
+    int32_t e_pad;           // message words per frame
+    int32_t p_words;         // posterior words per frame (n + the neutral cell, rounded up)
+    int32_t tab_lds_bytes;   // bytes of the workgroup's position table
+    int32_t lds_bytes_per_frame;
+};
+
 // Streamed ("HBM") BP engine: plain CSR of the Tanner graph, read through scalar loads.
 struct StreamTables {
     const int32_t *row_ptr;   // [m+1] edges in check-major order (variables ascending)

@@ -99,6 +99,26 @@ struct QcInfo {
 // largest Z >= 2 for which the matrix has this form (false: none)
 bool code_detect_qc(const Code &c, QcInfo &q);
 
+// ---- layered schedule for min-sum (bp_layered.hip) --------------------------------------------------------
+// A layer is a set of at most G checks of ONE degree that share no variable, handled by the G lanes of a frame group in one
+// step; the posteriors are updated in place after every layer.  Quasi-cyclic H: the layers are the block rows (a block
+// row of cyclic-shift blocks touches every variable at most once and all its checks have the degree "non-zero blocks of the
+// row"), cut into chunks of G when Z > G, and the device needs nothing but the (block column, shift) list of every block
+// row — edge j of check (R, k) is variable C_j*Z + (k + s_j) mod Z.  Any other H: greedy colouring of the checks into
+// conflict-free same-degree sets, with an explicit position table.
+struct LayeredLayout {
+    int G = 0;                 // lanes per frame (16, 20, 32 or 64)
+    int n_layers = 0;
+    bool qc = false;
+    int Z = 0;
+    int e_pad = 0;             // message words per frame: G * sum of the layers' degrees
+    std::vector<int32_t> layer;      // [n_layers][4] = {degree, message offset (words), checks in the layer, first proto entry | first row << 16}
+    std::vector<int32_t> proto;      // QC: per block row in use, degree x {block column, shift}
+    std::vector<int32_t> chk;        // [n_layers*G] check id of (layer, lane), -1 = none
+    std::vector<uint16_t> pos;       // [e_pad] variable of edge j of (layer, lane) at layer offset + j*G + lane (n = the neutral cell)
+};
+bool bp_layered_build(const Code &c, LayeredLayout &out);
+
 // ---- placement of the QP-ADMM problem on the threads / LDS of admm_block_kernel ------------------------------------
 // One workgroup of L threads owns a frame: thread l handles, in pass p, the variable var_of_slot[p*L + l] (v-update) and
 // the constraint group living in U slot p*L + l (row phase).  LDS: V[cell] (fp64/fp32 words) and U[slot][4 rows], tiled so

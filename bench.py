@@ -191,7 +191,7 @@ def cpu_baseline(algo, Hm, cws, snr, max_iter, target_s, alpha=0.0, mu=0.0, core
     ctx = mp.get_context("spawn")
     if cores is None:
         cores, core_info = usable_cores(ctx)
-    cal = 8
+    cal = 32 if algo == "bp" else 8   # BP frames take 1 ... 50 sweeps at -2 dB: a longer calibration sample
     ycal = o.transmit_frames(cws[np.arange(cal) % len(cws)], snr, first_seed=1)
     ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     with ctx.Pool(cores) as pool:
@@ -496,6 +496,9 @@ def ctor_table(A, a):
         "ms_fused": lambda dev: A.MinSumDecoder(a.iters, 0.75, early_exit=False, device=dev, lanes_per_frame=a.lanes),
         "ms_exit": lambda dev: A.MinSumDecoder(a.iters, 0.75, early_exit=True, device=dev, lanes_per_frame=a.lanes),
         "ms_streamed": lambda dev: A.MinSumDecoder(a.iters, 0.75, early_exit=False, device=dev, engine=eng_s),
+        # layered schedule: half the iterations for the same FER — a different algorithm, FER-level parity only
+        "ms_layered": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=False, device=dev, schedule=A.SCHEDULE_LAYERED),
+        "ms_layered_exit": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=True, device=dev, schedule=A.SCHEDULE_LAYERED),
         "qpadmm": lambda dev: A.QPADMMDecoder(a.alpha, a.mu, 100, 0.0, device=dev),          # eps 0: every frame runs 100 sweeps
         "qpadmm_exit": lambda dev: A.QPADMMDecoder(a.alpha, a.mu, 100, 1e-5, device=dev),
         "c5_block_ms": lambda dev: A.MinSumDecoder(50, 0.75, early_exit=False, device=dev),

@@ -239,6 +239,12 @@ int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t 
                             int32_t f64, int32_t engine, int32_t lanes_per_frame, double *c2v, double *v2c_mag,
                             double *v2c_sgn, double *post);
 
+/* diagnostics (host only, no device needed): the layers of ACG_LDPC_SCHEDULE_LAYERED for this matrix.  lanes = lanes per
+ * frame G, n_layers, qc_Z = circulant size if the block rows of a quasi-cyclic H were used (0: greedy colouring);
+ * chk (may be NULL) receives n_layers * G check ids in processing order (-1 = empty lane), at most cap entries.
+ * Returns 0, or non-zero if the matrix cannot be layered (message in acg_ldpc_last_error). */
+int acg_ldpc_debug_layers(const acg_ldpc_code *code, int32_t *lanes, int32_t *n_layers, int32_t *qc_Z, int32_t *chk, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

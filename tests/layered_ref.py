@@ -1,0 +1,60 @@
+"""numpy restatement (fp32, vectorised over frames) of the layered normalised min-sum of csrc/bp_layered.hip — the repo's OWN
+restatement: the layered schedule is not in the reference (algo/bp.h:183-199 floods) and neither is min-sum, so
+what this checks is that the kernel does what its description says, operation for operation; parity with the reference is
+FER-level only (tests/test_layered.py)."""
+import numpy as np
+
+
+def layered_minsum(Hm, layers, y, snr, max_iter, scale):
+    """Hm: m x n 0/1; layers: [n_layers, G] check ids (-1 = none) in processing order; y: frames x n float64 symbols.
+    -> bits [F, n] uint8 (zeros for failed frames), ok [F] uint8, iters [F] int32"""
+    Hm = np.asarray(Hm)
+    F, n = y.shape
+    var = 10.0 ** (-(snr / 10.0)) / 2.0
+    P = (2.0 * y.astype(np.float64) / var).astype(np.float32)          # channel.h:14-16, rounded to the kernel's fp32
+    edges = [np.nonzero(Hm[c])[0] for c in range(Hm.shape[0])]         # variables ascending
+    R = [np.zeros((F, len(e)), dtype=np.float32) for e in edges]
+    scale = np.float32(scale)
+    done = np.zeros(F, dtype=bool)
+    bits = np.zeros((F, n), dtype=np.uint8)
+    ok = np.zeros(F, dtype=np.uint8)
+    iters = np.full(F, max_iter, dtype=np.int32)
+    for it in range(1, max_iter + 1):
+        live = ~done
+        if not live.any():
+            break
+        loud = np.zeros(F, dtype=bool)
+        for layer in layers:
+            for c in layer:
+                if c < 0:
+                    continue
+                v = edges[c]
+                p = P[:, v]
+                q = p - R[c]
+                a = np.abs(q)
+                srt = np.sort(a, axis=1)
+                m1, m2 = srt[:, 0], (srt[:, 1] if a.shape[1] > 1 else np.full(F, np.inf, np.float32))
+                m1s, m2s = scale * m1, scale * m2
+                mag = np.where(a == m1[:, None], m2s[:, None], m1s[:, None]).astype(np.float32)
+                sq = np.signbit(q)
+                S = np.logical_xor.reduce(sq, axis=1)
+                neg = S[:, None] ^ sq
+                rn = np.where(neg, -mag, mag).astype(np.float32)
+                pn = (q + rn).astype(np.float32)
+                parity = np.logical_xor.reduce(np.signbit(p), axis=1)
+                loud |= parity | (np.signbit(pn) != np.signbit(p)).any(axis=1)
+                P[np.ix_(live, v)] = pn[live]
+                R[c][live] = rn[live]
+        newly = live & ~loud
+        bits[newly] = np.signbit(P[newly]).astype(np.uint8)
+        ok[newly] = 1
+        iters[newly] = it
+        done |= newly
+    rest = ~done
+    if rest.any() and max_iter > 0:     # out of iterations without a quiet round: one explicit syndrome pass
+        hb = np.signbit(P[rest]).astype(np.uint8)
+        good = ((hb @ Hm.T.astype(np.int64)) % 2 == 0).all(axis=1)
+        idx = np.nonzero(rest)[0][good]
+        bits[idx] = hb[good]
+        ok[idx] = 1
+    return bits, ok, iters

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""the HBM-resident streamed kernel on configs[4] (5000 x 10000, min-sum, 32768 frames, 50 sweeps) was seen at
+158 ms and at 179 ms.  One process, the same kernel instance, several allocation histories: which of them moves the time?
+
+  fresh        decoder created first thing in the process
+  after_free   after a large torch allocation was made and released (caching allocator emptied)
+  after_hold   while 64 / 128 GB of other device memory stay allocated (the slab workspace lands elsewhere)
+  recreate     the same again, new handle each time (the workspace is a new hipMalloc every time)
+Every line: workspace base address (and its offset inside a 2 MiB / 1 GiB frame), per-launch kernel ms.
+"""
+import os
+import re
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    import acg_alp_ldpc_amd as A
+    from acg_alp_ldpc_amd._lib import McCfg, check, lib
+    import ctypes as C
+    F = 32768
+    Hm = A.regular_ldpc(5000, 10000, 3, 6, seed=1)
+    H = A.ParityCheckMatrix(Hm)
+    n, nw = H.n, (H.n + 31) // 32
+    stream = torch.cuda.Stream()
+    cws = np.zeros((1, n), dtype=np.uint8)
+
+    def run(tag, launches=4):
+        dec = A.MinSumDecoder(50, 0.75, early_exit=False, engine=A.ENGINE_STREAMED)
+        desc = dec.describe(H)
+        base = int(re.search(r"workspace_base=(0x[0-9a-f]+)", desc).group(1), 16)
+        y = torch.empty((F, n), dtype=torch.float32, device="cuda")
+        bits = torch.zeros((F, nw), dtype=torch.int32, device="cuda")
+        ok = torch.zeros(F, dtype=torch.uint8, device="cuda")
+        its = torch.zeros(F, dtype=torch.int32, device="cuda")
+        h, _ = dec.handle(H)
+        cfg = McCfg()
+        cfg.frames, cfg.first_frame, cfg.snr, cfg.seed, cfg.noise = F, 0, 2.0, 1, 0
+        cfg.codewords, cfg.n_codewords = cws.ctypes.data, 1
+        check(lib().acg_ldpc_awgn_dev(h, C.byref(cfg), y.data_ptr(), stream.cuda_stream))
+        torch.cuda.synchronize()
+        ms = []
+        for k in range(launches + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            dec.decode_batch_dev(H, y.data_ptr(), False, F, 2.0, bits.data_ptr(), ok.data_ptr(), its.data_ptr(), stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if k:
+                ms.append(e0.elapsed_time(e1))
+        print("%-28s base=%#x  mod2MiB=%#8x mod1GiB=%#10x  ms=%s  ok=%d" % (tag, base, base % (2 << 20), base % (1 << 30),
+                                                                           " ".join("%.1f" % x for x in ms), int(ok.sum())), flush=True)
+        dec.close()
+        del y, bits, ok, its
+        return ms
+
+    run("fresh")
+    run("recreate_1")
+    t = torch.empty(48 << 30, dtype=torch.uint8, device="cuda")
+    t.fill_(1)
+    torch.cuda.synchronize()
+    del t
+    torch.cuda.empty_cache()
+    run("after_free_48GB")
+    hold = torch.empty(64 << 30, dtype=torch.uint8, device="cuda")
+    hold.fill_(1)
+    run("while_holding_64GB")
+    hold2 = torch.empty(64 << 30, dtype=torch.uint8, device="cuda")
+    hold2.fill_(2)
+    run("while_holding_128GB")
+    del hold, hold2
+    torch.cuda.empty_cache()
+    run("after_release")
+    # many small allocations first (fragmented free list), then the workspace
+    small = [torch.empty(3 << 20, dtype=torch.uint8, device="cuda") for _ in range(2000)]
+    del small[::2]
+    run("after_fragmenting")
+    del small
+    torch.cuda.empty_cache()
+    run("recreate_last")
+
+
+if __name__ == "__main__":
+    main()
