@@ -74,6 +74,7 @@ SYMBOLS = {
     "acg_ldpc_transmit_host": (C.c_int, [_vp, _i64, _i32, _i64, _i64, _f64, _vp]),
     "acg_ldpc_llr_variance": (_f64, [_f64]),
     "acg_ldpc_awgn_dev": (C.c_int, [_vp, C.POINTER(McCfg), _vp, _vp]),
+    "acg_ldpc_debug_ring_tasks": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _i64, _vp]),
     "acg_ldpc_debug_layers": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp, _i64]),
     "acg_ldpc_debug_phi": (C.c_int, [_vp, _vp, _i32, _i32]),
     "acg_ldpc_debug_bp_trace": (C.c_int, [_vp, _vp, _i32, _f64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -42,6 +42,7 @@ const void *bp_layered_kernel_ptr(int G, int waves);
 hipError_t bp_layered_launch(const void *kernel, const LayerTables &t, const DecodeArgs &a, int grid, int block, size_t lds, hipStream_t s);
 const void *bp_streamed_ptr(int algo, int f64);
 const void *bp_streamed_ring_ptr(int algo, bool nt);
+const void *bp_streamed_ring_ptr_dbg();
 hipError_t bp_streamed_ring_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid, hipStream_t s);
 hipError_t bp_streamed_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid,
                               int block, hipStream_t s);
@@ -197,6 +198,84 @@ struct HostPipe {
 
 using namespace acg;
 
+// Workspace of the streamed engine as separately created physical chunks mapped into one virtual range in a shuffled order
+// (HIP virtual-memory-management API).  Why: see decoder_setup_streamed — a physically CONTIGUOUS backing of the slabs is the
+// slow mode of bp_streamed_ring_kernel on slabs beyond the Infinity Cache (181 ms against 158 ms per launch on configs[4]),
+// and plain hipMalloc hands out either kind depending on the allocation history of the process.
+struct ScatteredAlloc {
+    void *va = nullptr;
+    size_t bytes = 0, chunk = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<char> mapped;
+    void release() {
+        if (!va) return;
+        for (size_t i = 0; i < handles.size(); i++) {
+            if (mapped[i]) (void) hipMemUnmap((char *) va + i * chunk, chunk);
+        }
+        for (auto &h : handles) (void) hipMemRelease(h);
+        (void) hipMemAddressFree(va, bytes);
+        va = nullptr;
+        handles.clear();
+        mapped.clear();
+    }
+    // -> true on success (va usable, read/write from `dev`)
+    bool create(size_t want, size_t chunk_bytes, int dev, bool shuffle) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return false;
+        chunk = (std::max(chunk_bytes, gran) + gran - 1) / gran * gran;
+        const size_t n = (want + chunk - 1) / chunk;
+        bytes = n * chunk;
+        if (hipMemAddressReserve(&va, bytes, 0, nullptr, 0) != hipSuccess) {
+            va = nullptr;
+            return false;
+        }
+        handles.reserve(n);
+        mapped.assign(n, 0);
+        for (size_t i = 0; i < n; i++) {
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
+                release();
+                return false;
+            }
+            handles.push_back(h);
+        }
+        // physical chunk i (creation order: neighbours in physical memory more often than not) -> virtual slot perm[i]
+        std::vector<size_t> perm(n);
+        for (size_t i = 0; i < n; i++) perm[i] = i;
+        if (shuffle) {
+            uint64_t x = 0x9E3779B97F4A7C15ull;  // fixed seed: the layout of a given size is the same in every process
+            for (size_t i = n; i > 1; i--) {
+                x ^= x << 13;
+                x ^= x >> 7;
+                x ^= x << 17;
+                std::swap(perm[i - 1], perm[(size_t) (x % i)]);
+            }
+        }
+        std::vector<hipMemGenericAllocationHandle_t> by_slot(n);
+        for (size_t i = 0; i < n; i++) by_slot[perm[i]] = handles[i];
+        handles = by_slot;
+        for (size_t s = 0; s < n; s++) {
+            if (hipMemMap((char *) va + s * chunk, chunk, 0, handles[s], 0) != hipSuccess) {
+                release();
+                return false;
+            }
+            mapped[s] = 1;
+        }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemSetAccess(va, bytes, &acc, 1) != hipSuccess) {
+            release();
+            return false;
+        }
+        return true;
+    }
+};
+
 struct acg_ldpc_code {
     Code c;
 };
@@ -234,6 +313,7 @@ struct acg_ldpc_decoder {
     int sring_per_cu = 2;
     bool sring_nt = false;  // ring instance with non-temporal slab accesses (slabs beyond the Infinity Cache)
     uint32_t *sws = nullptr;
+    ScatteredAlloc sws_scattered;  // backing of sws when it was made of shuffled physical chunks (else sws is a hipMalloc)
     int sgrid = 0;
     // ADMM
     AdmmDevice *admm = nullptr;
@@ -407,57 +487,10 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
     // LDS-DMA ring engine (fp32, node degrees that fit a ring slot): cut the sweeps into tasks
     size_t hb_bytes = (size_t) t.nwords * 64 * 4;  // HB[nwords][64] (u32)
     if (!d->f64 && c.max_cdeg <= RING_MAX_CDEG && c.max_vdeg <= RING_MAX_VDEG && getenv("ACG_STREAM_NO_RING") == nullptr) {
-        struct Task { int first, cnt, base, lines; };
-        std::vector<Task> ct, vt;
-        for (int i = 0; i < c.m;) {
-            Task k{i, 0, c.row_ptr[i], 0};
-            while (i < c.m && k.cnt < 16 && k.lines + (c.row_ptr[i + 1] - c.row_ptr[i]) <= RING_SLOT_LINES) {
-                k.lines += c.row_ptr[i + 1] - c.row_ptr[i];
-                k.cnt++;
-                i++;
-            }
-            ct.push_back(k);
-        }
-        for (int v = 0; v < c.n;) {
-            Task k{v, 0, c.col_ptr[v], 0};
-            while (v < c.n && k.cnt < 4 && k.lines + (c.col_ptr[v + 1] - c.col_ptr[v]) <= RING_VAR_EDGE_LINES) {
-                k.lines += c.col_ptr[v + 1] - c.col_ptr[v];
-                k.cnt++;
-                v++;
-            }
-            vt.push_back(k);
-        }
-        // vector-memory operations a task certainly issues: loads (one LDS-DMA instruction per four lines, + the LLR lines of
-        // a variable task) and message stores (one per line); the hard-decision byte of a variable task is predicated and
-        // therefore not counted.  wait(i) for the i-th task of a wavefront: see bp_streamed_ring_kernel.
-        auto pack = [&](const std::vector<Task> &tk, bool var) {
-            std::vector<int32_t> out(4 * std::max<size_t>(tk.size(), 1), 0);
-            for (int w = 0; w < RING_WAVES; w++) {
-                std::vector<int> seq;
-                for (int i = w; i < (int) tk.size(); i += RING_WAVES) seq.push_back(i);
-                auto opsL = [&](int i) { return (tk[seq[i]].lines + 3) / 4 + (var ? 1 : 0); };
-                auto opsS = [&](int i) { return tk[seq[i]].lines; };
-                for (int i = 0; i < (int) seq.size(); i++) {
-                    int wl = 0, wsn = 0;
-                    for (int k = i + 1; k <= std::min<int>(i + RING_SLOTS - 1, (int) seq.size() - 1); k++) wl += opsL(k);
-                    for (int j = std::max(0, i - RING_SLOTS + 1); j <= i - 1; j++) wsn += opsS(j);
-                    const Task &k = tk[seq[i]];
-                    out[4 * seq[i] + 0] = k.first;
-                    out[4 * seq[i] + 1] = k.cnt;
-                    out[4 * seq[i] + 2] = k.base;
-                    out[4 * seq[i] + 3] = k.lines | (std::min(wl + wsn, 63) << 8) | (std::min(wl, 63) << 16);
-                }
-            }
-            return out;
-        };
-        std::vector<int32_t> hct = pack(ct, false), hvt = pack(vt, true), hvw(std::max(t.nwords, 1), 0);
-        {
-            size_t ti = 0;
-            for (int k = 0; k < t.nwords; k++) {
-                while (ti + 1 < vt.size() && vt[ti].first + vt[ti].cnt <= 32 * k) ti++;
-                hvw[k] = (int32_t) ti;
-            }
-        }
+        RingTasks rt;
+        ring_tasks_build(c, rt);
+        const std::vector<int32_t> &hct = rt.ctask, &hvt = rt.vtask, &hvw = rt.vtask_of_word;
+        struct { size_t n; size_t size() const { return n; } } ct{(size_t) rt.n_ctask}, vt{(size_t) rt.n_vtask};
         std::vector<int32_t> ce = c.col_edge;
         ce.resize(ce.size() + 4, 0);  // the gather reads its edge ids four at a time
         UP32S(hct, ctask)
@@ -478,6 +511,7 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
 #undef UP32S
     // per workgroup: M[E][64] + LLR[n][64] (T) + hard decisions
     t.ws_words_per_wave = (int64_t) (((size_t) (c.E + c.n) * 64 * ts + hb_bytes + 255) / 256 * 64);
+    if (const char *pad = getenv("ACG_STREAM_SLAB_PAD")) t.ws_words_per_wave += (int64_t) (atol(pad) / 256 * 64);  // developer A/B: slab stride + pad bytes
     d->block = 256;
     d->frames_per_block = 64;  // one 64-frame tile per workgroup at a time
     const int algo = (d->p.algo == ACG_LDPC_BP_MINSUM) ? 1 : 0;
@@ -496,7 +530,34 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
         set_error("internal: streamed-engine slab size not set");
         return 11;
     }
-    HIP_OK(hipMalloc((void **) &d->sws, ws_bytes));
+    {
+        // Where the slabs live decides the rate of the ring kernel once they exceed the Infinity Cache (configs[4]: 768 slabs of
+        // 10.4 MB; tools/stream_bimodal.py, profiles/r03_stream_bimodal.txt, one process, same kernel instance, same virtual address):
+        //   hipMalloc                             158 ms or 181 ms per launch, fixed for the life of the allocation, decided anew by
+        //                                         every hipMalloc (this is round 2's "158 or 179 ms depending on the box")
+        //   hipDeviceMallocContiguous             181 ms, 12 of 12 allocations: the slow mode IS the physically contiguous backing
+        //   physical chunks mapped into one       149 ms, 20 of 20, chunk size 2 / 32 / 256 MiB, shuffled or in creation order
+        //   virtual range (hipMemCreate/hipMemMap)
+        // The slab stride does not matter in any of them.  So the workspace is built from 64 MiB chunks (shuffled with a fixed
+        // seed); plain hipMalloc remains the fallback and the small-workspace path.  ACG_STREAM_WS_ALLOC = 0 / 1 / 2 / 3 forces
+        // hipMalloc / contiguous / shuffled chunks / chunks in creation order (developer A/B only).
+        const char *wa = getenv("ACG_STREAM_WS_ALLOC");
+        const int mode = wa ? atoi(wa) : (ws_bytes >= ((size_t) 64 << 20) ? 2 : 0);
+        hipError_t e = hipErrorUnknown;
+        if (mode == 1) e = hipExtMallocWithFlags((void **) &d->sws, ws_bytes, hipDeviceMallocContiguous);
+        if (mode >= 2) {
+            const char *cm = getenv("ACG_STREAM_WS_CHUNK_MB");
+            const size_t chunk = (size_t) (cm ? atol(cm) : 64) << 20;
+            if (d->sws_scattered.create(ws_bytes, chunk, d->device, mode == 2)) {
+                d->sws = (uint32_t *) d->sws_scattered.va;
+                e = hipSuccess;
+            }
+        }
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            HIP_OK(hipMalloc((void **) &d->sws, ws_bytes));
+        }
+    }
     d->grid_cap[0] = d->grid_cap[1] = d->sgrid;
     return 0;
 }
@@ -908,7 +969,8 @@ void acg_ldpc_decoder_destroy(acg_ldpc_decoder *d) {
     if (d->stream) (void) hipStreamSynchronize(d->stream);
     for (void *p : d->dev_allocs) (void) hipFree(p);
     if (d->admm) admm_device_destroy(d->admm);
-    if (d->sws) (void) hipFree(d->sws);
+    if (d->sws_scattered.va) d->sws_scattered.release();
+    else if (d->sws) (void) hipFree(d->sws);
     if (d->mc_y) (void) hipFree(d->mc_y);
     if (d->st_y) (void) hipFree(d->st_y);
     if (d->st_bits) (void) hipFree(d->st_bits);
@@ -953,7 +1015,8 @@ static std::string describe(const acg_ldpc_decoder *d) {
         snprintf(b, sizeof b, "%s engine=streamed kernel=%s%s f64=%d slab_bytes=%zu slabs=%d workspace_bytes=%zu workspace_base=%p "
                                "workgroups_per_cu=%d schedule=%s",
                  algo, d->sring ? "bp_streamed_ring_kernel" : "bp_streamed_kernel", d->sring ? (d->sring_nt ? "<NT>" : "<default-policy>") : "",
-                 d->f64, slab, d->sgrid, slab * (size_t) d->sgrid, (void *) d->sws, d->sring ? d->sring_per_cu : 2, "flooding");
+                 d->f64, slab, d->sgrid, slab * (size_t) d->sgrid, (void *) d->sws, d->sring ? d->sring_per_cu : 2,
+                 d->sws_scattered.va ? "flooding workspace=mapped-chunks" : "flooding workspace=hipMalloc");
     } else {
         snprintf(b, sizeof b, "%s engine=fused kernel=%s lanes_per_frame=%d f64=%d block=%d frames_per_block=%d lds_block=%zu grid_cap=%d "
                                "idx_lds=%d idx_reg=%d schedule=%s",
@@ -1019,9 +1082,15 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
         while (W < 8 && tiles * W < 8 * (int64_t) d->cu_count) W <<= 1;
         const int per_cu = (W <= 4) ? 2 : 1;
         int grid = (int) std::min<int64_t>(tiles, (int64_t) per_cu * d->cu_count);
-        if (d->sring && !a.dbg_c2v && !a.dbg_v2c) {
+        if (d->sring) {
+            // traces (acg_ldpc_debug_bp_trace) run the debug instance of the SAME kernel: its sweeps, its counted waits
+            const void *kp = d->sring;
+            if (a.dbg_c2v || a.dbg_v2c) {
+                kp = bp_streamed_ring_ptr_dbg();
+                HIP_OK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+            }
             grid = (int) std::min<int64_t>(tiles, (int64_t) d->sring_per_cu * d->cu_count);
-            HIP_OK(bp_streamed_ring_launch(d->sring, d->stab, a, d->sws, grid, s));
+            HIP_OK(bp_streamed_ring_launch(kp, d->stab, a, d->sws, grid, s));
         } else {
             HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
         }
@@ -1715,6 +1784,31 @@ int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t 
                             int32_t f64, int32_t engine, int32_t lanes_per_frame, double *c2v, double *v2c_mag,
                             double *v2c_sgn, double *post) {
     return guarded([&] { return acg_ldpc_debug_bp_trace_impl(code, y, frames, snr, iters, f64, engine, lanes_per_frame, c2v, v2c_mag, v2c_sgn, post); });
+}
+
+int acg_ldpc_debug_ring_tasks(const acg_ldpc_code *code, int32_t *n_ctask, int32_t *n_vtask, int32_t *ctask, int32_t *vtask, int64_t cap,
+                              int32_t *consts) {
+    return guarded([&]() -> int {
+        if (!code) {
+            set_error("null argument");
+            return 1;
+        }
+        RingTasks rt;
+        ring_tasks_build(code->c, rt);
+        if (n_ctask) *n_ctask = rt.n_ctask;
+        if (n_vtask) *n_vtask = rt.n_vtask;
+        if (ctask)
+            for (int64_t i = 0; i < std::min<int64_t>(cap, (int64_t) rt.ctask.size()); i++) ctask[i] = rt.ctask[(size_t) i];
+        if (vtask)
+            for (int64_t i = 0; i < std::min<int64_t>(cap, (int64_t) rt.vtask.size()); i++) vtask[i] = rt.vtask[(size_t) i];
+        if (consts) {
+            consts[0] = RING_WAVES;
+            consts[1] = RING_SLOTS;
+            consts[2] = RING_SLOT_LINES;
+            consts[3] = RING_VAR_EDGE_LINES;
+        }
+        return 0;
+    });
 }
 
 int acg_ldpc_debug_layers(const acg_ldpc_code *code, int32_t *lanes, int32_t *n_layers, int32_t *qc_Z, int32_t *chk, int64_t cap) {

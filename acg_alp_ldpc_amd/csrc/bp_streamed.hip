@@ -538,7 +538,10 @@ struct RingPass {
     }
 
 // NT: non-temporal loads and stores for slabs that cannot stay in the 256 MiB Infinity Cache between two sweeps anyway
-template <int ALGO, bool NT>
+// DBG (tests only, acg_ldpc_debug_bp_trace): the message slab of the first tile is copied out after the check sweep and after the
+// variable sweep of the last iteration (the messages live in memory, so the trace is a copy of M), with the posteriors
+// LLR + sum of the dumped c->v words (bp.h:85-90); the product instances are compiled with DBG = false.
+template <int ALGO, bool NT, bool DBG = false>
 __global__ void __launch_bounds__(RING_WAVES * 64, (RING_LDS_BYTES <= 32 * 1024 ? 5 : (RING_LDS_BYTES <= 40 * 1024 ? 4 : (RING_LDS_BYTES <= 52 * 1024 ? 3 : 2)))) bp_streamed_ring_kernel(const StreamTables t, const DecodeArgs a, uint32_t *ws) {
     using T = float;
     using B = FpBits<float>;
@@ -649,6 +652,10 @@ __global__ void __launch_bounds__(RING_WAVES * 64, (RING_LDS_BYTES <= 32 * 1024 
             }
             const bool done = latched || !valid;
             if (sonly) break;
+            if (DBG && a.dbg_c2v && tile == 0 && it == a.max_iter - 1) {  // c->v words of the last sweep (the barrier above drained the stores)
+                T *dc = reinterpret_cast<T *>(a.dbg_c2v);
+                for (int e = w; e < t.E; e += W) dc[(size_t) e * 64 + lane] = M[(size_t) e * 64 + lane];
+            }
             if (a.early_exit && __ballot(!done) == 0ull) break;  // identical in every wave of the block
             // ---- variable sweep (bp.h:160-169) + posterior hard decisions (bp.h:191-193) ----
             for (int i = 0; i < R - 1 && i < n_vt; ++i) issue_var(i);
@@ -679,6 +686,19 @@ __global__ void __launch_bounds__(RING_WAVES * 64, (RING_LDS_BYTES <= 32 * 1024 
                 if (!latched) HB[(size_t) ti * 64 + lane] = (uint8_t) bits;  // frozen once the frame has converged
             }
             __syncthreads();
+            if (DBG && a.dbg_v2c && tile == 0 && it == a.max_iter - 1) {  // v->c words + posteriors of the last sweep
+                T *dv = reinterpret_cast<T *>(a.dbg_v2c);
+                T *dc = reinterpret_cast<T *>(a.dbg_c2v);
+                T *dp = reinterpret_cast<T *>(a.dbg_post);
+                for (int e = w; e < t.E; e += W) dv[(size_t) e * 64 + lane] = M[(size_t) e * 64 + lane];
+                for (int v = w; v < t.n; v += W) {
+                    T sum = 0;  // estimate() = llr + sum of the c->v mailbox (bp.h:85-90), from the dumped c->v words
+                    for (int k = sload(t.col_ptr, v); k < sload(t.col_ptr, v + 1); ++k)
+                        sum += dc[(size_t) sload(t.col_edge, k) * 64 + lane];
+                    dp[(size_t) v * 64 + lane] = LLR[(size_t) v * 64 + lane] + sum;
+                }
+                __syncthreads();
+            }
         }
         // ---- outputs: words assembled from the per-task bytes ----
         if (valid) {
@@ -715,6 +735,9 @@ const void *bp_streamed_ring_ptr(int algo, bool nt) {
     if (nt) return algo == 0 ? (const void *) bp_streamed_ring_kernel<0, true> : (const void *) bp_streamed_ring_kernel<1, true>;
     return algo == 0 ? (const void *) bp_streamed_ring_kernel<0, false> : (const void *) bp_streamed_ring_kernel<1, false>;
 }
+
+// debug instance (sum-product, default cache policy): the arithmetic and the counted waits are those of the product kernel
+const void *bp_streamed_ring_ptr_dbg() { return (const void *) bp_streamed_ring_kernel<0, false, true>; }
 
 hipError_t bp_streamed_ring_launch(const void *kernel, const StreamTables &t, const DecodeArgs &a, uint32_t *ws, int grid, hipStream_t s) {
     StreamTables tt = t;

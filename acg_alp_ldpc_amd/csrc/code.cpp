@@ -560,6 +560,66 @@ bool code_detect_qc(const Code &c, QcInfo &q) {
 }
 
 // ---------------------------------------------------------------- QP-ADMM block-kernel placement
+// Task tables of the LDS-DMA ring engine (see RingTasks; consumed by bp_streamed_ring_kernel).
+void ring_tasks_build(const Code &c, RingTasks &o) {
+    struct Task { int first, cnt, base, lines; };
+    std::vector<Task> ct, vt;
+    for (int i = 0; i < c.m;) {
+        Task k{i, 0, c.row_ptr[i], 0};
+        while (i < c.m && k.cnt < 16 && k.lines + (c.row_ptr[i + 1] - c.row_ptr[i]) <= RING_SLOT_LINES) {
+            k.lines += c.row_ptr[i + 1] - c.row_ptr[i];
+            k.cnt++;
+            i++;
+        }
+        ct.push_back(k);
+    }
+    for (int v = 0; v < c.n;) {
+        Task k{v, 0, c.col_ptr[v], 0};
+        while (v < c.n && k.cnt < 4 && k.lines + (c.col_ptr[v + 1] - c.col_ptr[v]) <= RING_VAR_EDGE_LINES) {
+            k.lines += c.col_ptr[v + 1] - c.col_ptr[v];
+            k.cnt++;
+            v++;
+        }
+        vt.push_back(k);
+    }
+    // vector-memory operations a task certainly issues: loads (one LDS-DMA instruction per four lines, + the LLR lines of
+    // a variable task) and message stores (one per line); the hard-decision byte of a variable task is predicated and
+    // therefore not counted.  wait(i) for the i-th task of a wavefront: see bp_streamed_ring_kernel.
+    auto pack = [&](const std::vector<Task> &tk, bool var) {
+        std::vector<int32_t> out(4 * std::max<size_t>(tk.size(), 1), 0);
+        for (int w = 0; w < RING_WAVES; w++) {
+            std::vector<int> seq;
+            for (int i = w; i < (int) tk.size(); i += RING_WAVES) seq.push_back(i);
+            auto opsL = [&](int i) { return (tk[seq[i]].lines + 3) / 4 + (var ? 1 : 0); };
+            auto opsS = [&](int i) { return tk[seq[i]].lines; };
+            for (int i = 0; i < (int) seq.size(); i++) {
+                int wl = 0, wsn = 0;
+                for (int k = i + 1; k <= std::min<int>(i + RING_SLOTS - 1, (int) seq.size() - 1); k++) wl += opsL(k);
+                for (int j = std::max(0, i - RING_SLOTS + 1); j <= i - 1; j++) wsn += opsS(j);
+                const Task &k = tk[seq[i]];
+                out[4 * seq[i] + 0] = k.first;
+                out[4 * seq[i] + 1] = k.cnt;
+                out[4 * seq[i] + 2] = k.base;
+                out[4 * seq[i] + 3] = k.lines | (std::min(wl + wsn, 63) << 8) | (std::min(wl, 63) << 16);
+            }
+        }
+        return out;
+    };
+    const int nwords = (c.n + 31) / 32;
+    o.ctask = pack(ct, false);
+    o.vtask = pack(vt, true);
+    o.vtask_of_word.assign((size_t) std::max(nwords, 1), 0);
+    {
+        size_t ti = 0;
+        for (int k = 0; k < nwords; k++) {
+            while (ti + 1 < vt.size() && vt[ti].first + vt[ti].cnt <= 32 * k) ti++;
+            o.vtask_of_word[(size_t) k] = (int32_t) ti;
+        }
+    }
+    o.n_ctask = (int) ct.size();
+    o.n_vtask = (int) vt.size();
+}
+
 // Layers of the layered min-sum schedule (see LayeredLayout).
 bool bp_layered_build(const Code &c, LayeredLayout &o) {
     o = LayeredLayout();

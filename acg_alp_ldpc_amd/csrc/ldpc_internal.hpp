@@ -6,6 +6,8 @@
 #include <string>
 #include <vector>
 
+#include "kernels.hpp"
+
 namespace acg {
 
 void set_error(const std::string &msg);
@@ -98,6 +100,16 @@ struct QcInfo {
 };
 // largest Z >= 2 for which the matrix has this form (false: none)
 bool code_detect_qc(const Code &c, QcInfo &q);
+
+// ---- task tables of the LDS-DMA ring engine (bp_streamed_ring_kernel) ---------------------------------------------------
+// The sweeps cut into tasks of at most RING_SLOT_LINES message lines; task i of a sweep belongs to wavefront i mod RING_WAVES.
+// int4 per task (see StreamTables in kernels.hpp); the counted waits are what the kernel hands to s_waitcnt vmcnt(N):
+// N = vector-memory operations CERTAINLY issued behind the task's loads when its data is needed.
+struct RingTasks {
+    std::vector<int32_t> ctask, vtask, vtask_of_word;
+    int n_ctask = 0, n_vtask = 0;
+};
+void ring_tasks_build(const Code &c, RingTasks &out);
 
 // ---- layered schedule for min-sum (bp_layered.hip) --------------------------------------------------------
 // A layer is a set of at most G checks of ONE degree that share no variable, handled by the G lanes of a frame group in one

@@ -231,13 +231,21 @@ int acg_ldpc_debug_phi(const void *x_host, void *out_host, int32_t n, int32_t f6
  * the exit test, for 1..64 frames (y: frames*n doubles).  Outputs are frames*E (edge order: check-major, variables
  * ascending) / frames*n doubles: c2v = messages check->variable, (v2c_mag, v2c_sgn) = the (phi(|x|), sign) pairs
  * variable->check, post = VNode::estimate() (bp.h:85-90).
- * engine: ACG_LDPC_ENGINE_STREAMED (or AUTO) = the HBM engine; ACG_LDPC_ENGINE_FUSED = the LDS-resident kernels, read out
+ * engine: ACG_LDPC_ENGINE_STREAMED (or AUTO) = the HBM engine (fp32: a debug instance of the LDS-DMA ring kernel that ships, with
+ * its own sweeps and counted waits; fp64 and node degrees above 12: the register-staged kernel); ACG_LDPC_ENGINE_FUSED = the LDS-resident kernels, read out
  * of LDS by a debug instance of the same kernel: lanes_per_frame 0/32/64 = wavefront groups (node degree <= 8, n <= 12
  * passes), 256 = one workgroup per frame (index table in LDS).  For the fused kernels `post` is the channel LLR plus the
  * sum of the dumped c2v words, added on the host. */
 int acg_ldpc_debug_bp_trace(const acg_ldpc_code *code, const double *y, int32_t frames, double snr, int32_t iters,
                             int32_t f64, int32_t engine, int32_t lanes_per_frame, double *c2v, double *v2c_mag,
                             double *v2c_sgn, double *post);
+
+/* diagnostics (host only, no device needed): the task tables of the streamed engine's LDS-DMA ring kernel, 4 int32 per task
+ * {first node, nodes, first line / col_ptr entry, lines | wait << 8 | wait_without_stores << 16}; consts (4 int32) receives
+ * {wavefronts per workgroup, ring slots, lines per slot, edge lines per variable task}.  tests/test_ring_waits.py replays
+ * the kernel's issue order against the counted waits. */
+int acg_ldpc_debug_ring_tasks(const acg_ldpc_code *code, int32_t *n_ctask, int32_t *n_vtask, int32_t *ctask, int32_t *vtask,
+                              int64_t cap, int32_t *consts);
 
 /* diagnostics (host only, no device needed): the layers of ACG_LDPC_SCHEDULE_LAYERED for this matrix.  lanes = lanes per
  * frame G, n_layers, qc_Z = circulant size if the block rows of a quasi-cyclic H were used (0: greedy colouring);

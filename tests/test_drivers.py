@@ -44,6 +44,46 @@ def test_drivers_build_and_qc_roundtrip(drivers, oracle):
     assert out.returncode != 0 or "Z=16" in out.stdout
 
 
+def test_optimize_driver_proposal_sequence_is_the_references(drivers):
+    """N3 pin (CPU): the first 64 proposals of acg_optimize_h — block row, block column, presence, shift — equal those of the
+    reference's PermutationsMatrix::random_permute (optimize_H.cpp:66-75) under std::mt19937(239) (optimize_H.cpp:132), for the
+    all-rejected and the all-accepted chain, on H05 and optimalH.  The fixture was written by oracle/make_golden_optimize.py
+    from the real reference compiled as it lies (oracle/ref_optimize_shim.cpp).  Acceptance itself cannot be pinned (it rides
+    on a 200-thread seed race)."""
+    import json
+    fix = json.load(open(os.path.join(ROOT, "tests", "golden", "optimize_h_proposals.json")))
+    assert len(fix["cases"]) == 8
+    for case in fix["cases"]:
+        cmd = [os.path.join(drivers, "acg_optimize_h"), "--init", os.path.join(DATA, case["matrix"]), "--Z", str(case["Z"]),
+               "--seed", str(case["seed"]), "--dump-proposals", str(len(case["proposals"]))]
+        if case["accept_all"]:
+            cmd.append("--accept-all")
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        got = [[int(x) for x in line.split()] for line in out.stdout.strip().split("\n")]
+        assert got == case["proposals"], (case["matrix"], case["seed"], case["accept_all"])
+    # the two chains really differ (a proposal on a block mutated earlier sees the mutated presence)
+    assert fix["cases"][0]["proposals"] != fix["cases"][1]["proposals"]
+
+
+def test_reference_shim_reproduces_the_fixture():
+    """the fixture against the real reference where it is available (this container); skipped on the GPU box"""
+    import ctypes as C
+    import json
+    import numpy as np
+    so = os.path.join(ROOT, "oracle", "_ref", "libacg_ref_opt.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libacg_ref_opt.so not built (no /root/reference here)")
+    lib = C.CDLL(so)
+    lib.ref_opt_proposals.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_void_p]
+    fix = json.load(open(os.path.join(ROOT, "tests", "golden", "optimize_h_proposals.json")))
+    for case in fix["cases"]:
+        out = np.zeros((len(case["proposals"]), 4), dtype=np.int32)
+        rc = lib.ref_opt_proposals(os.path.join(DATA, case["matrix"]).encode(), case["Z"], case["seed"], len(out), case["accept_all"],
+                                   out.ctypes.data_as(C.c_void_p))
+        assert rc == 0 and out.tolist() == case["proposals"]
+
+
 @pytest.mark.gpu
 def test_eval_driver_reproduces_reference_known_answers(drivers, tmp_path):
     """main.cpp loop with the reference's exact frames: H05, BP(50) and QP-ADMM(1.95,0.5,100) at -2 dB, 1000 frames,

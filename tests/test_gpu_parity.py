@@ -620,22 +620,29 @@ def test_config5_block_kernel_variants_agree_near_threshold(A, oracle):
     assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
 
 
-@pytest.mark.parametrize("engine", ["streamed", "fused", "fused_block256"])
+@pytest.mark.parametrize("engine", ["streamed_ring", "streamed_regs", "fused", "fused_block256"])
 @pytest.mark.parametrize("name", MATS)
 @pytest.mark.parametrize("snr", [-2.0, 2.0])
-def test_bp_soft_messages_vs_reference_trace(A, pcm, name, snr, engine):
+def test_bp_soft_messages_vs_reference_trace(A, pcm, name, snr, engine, monkeypatch):
     """SURVEY §8(c) stated tolerance: soft LLR-domain values after iterations 1 and 2 within
     1e-4 * max(1, |x|) of the real reference (fp32) for finite, unsaturated (|x| < 15) values; fp64: 1e-9.
-    Every engine has its own sweep code (StreamPass / BpPass wave groups / BpPass workgroup-per-frame with the syndrome
-    merged into the check sweep), so each is traced: the fused ones by a debug instance that copies the message words
-    out of LDS."""
+    Every engine has its own sweep code, so each is traced by a debug instance of the kernel that ships:
+      streamed_ring   bp_streamed_ring_kernel (RingPass + the counted vmcnt waits; what the fp32 streamed engine runs) — the slab
+                      of the first tile copied out of memory
+      streamed_regs   bp_streamed_kernel (StreamPass; fp64, and fp32 for node degrees 13-16 that do not fit a ring slot; forced
+                      here with ACG_STREAM_NO_RING)
+      fused / fused_block256   BpPass wave groups / workgroup-per-frame with the syndrome merged into the check sweep — the
+                      message words copied out of LDS."""
     g = load(name, snr)
     H = pcm[name]
     E = H.E
     nf = g["trace1_c2v"].shape[0]
     y = np.ascontiguousarray(g["y"][:nf])
-    eng, lpf = {"streamed": (A.ENGINE_STREAMED, 0), "fused": (A.ENGINE_FUSED, 0), "fused_block256": (A.ENGINE_FUSED, 256)}[engine]
-    for f64, tol in ((0, 1e-4), (1, 1e-9)):
+    eng, lpf = {"streamed_ring": (A.ENGINE_STREAMED, 0), "streamed_regs": (A.ENGINE_STREAMED, 0), "fused": (A.ENGINE_FUSED, 0),
+                "fused_block256": (A.ENGINE_FUSED, 256)}[engine]
+    if engine == "streamed_regs":
+        monkeypatch.setenv("ACG_STREAM_NO_RING", "1")
+    for f64, tol in (((0, 1e-4),) if engine == "streamed_ring" else ((0, 1e-4), (1, 1e-9))):
         for it in (1, 2):
             c2v, mag, sgn = (np.zeros((nf, E)) for _ in range(3))
             post = np.zeros((nf, H.n))

@@ -157,4 +157,5 @@ def test_layered_25_not_worse_than_flooding_50(A, matrices, name):
         print("%s %+.1f dB: FER layered-25 %.5f  flooding-50 %.5f  sum-product-50 %.5f; mean iterations %.2f / %.2f / %.2f; pseudo %d / %d"
               % (name, snr, fl, ff, rs.FER(), rl.mean_iters(), rf.mean_iters(), rs.mean_iters(), rl.pseudo, rf.pseudo))
         assert fl <= ff + slack, (name, snr, fl, ff)
-        assert rl.mean_iters() < 0.7 * rf.mean_iters()        # about half the sweeps
+        # fewer sweeps: about half while a frame is still moving, plus the one quiet round that proves convergence
+        assert rl.mean_iters() < 0.85 * rf.mean_iters()

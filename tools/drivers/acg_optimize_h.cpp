@@ -2,6 +2,9 @@
 // random block mutated per proposal, accepted when the QP-ADMM FER at -3 dB over 1000 frames drops) on the device.
 //   acg_optimize_h [--init data/H05.txt | --random 8,14] [--Z 20] [--iters 10000] [--tests 1000] [--snr -3]
 //                  [--alpha 1.95 --mu 0.5 --admm-iters 1000] [--seed 239] [--out optimalH.txt] [--noise host|device]
+//                  [--dump-proposals N [--accept-all]]   host only: print "row col present shift" of the first N proposals
+//                                                        (every one rejected, or every one accepted) and stop — pinned against
+//                                                        the reference's own random_permute in tests/test_drivers.py
 // Every proposal is a fresh H: graph analysis, generator (GetOrtogonal) and decoder are rebuilt per proposal through
 // the C ABI; a proposal whose generator does not exist scores FER = 1 (optimize_H.cpp:17-19).
 #include <iostream>
@@ -51,15 +54,16 @@ struct QcMatrix {  // quasi-cyclic description: block mask + one shift per prese
     }
 
     // one mutation (optimize_H.cpp:66-75): pick a block; flip its presence if it is absent or with probability 1/2;
-    // redraw its shift
+    // redraw its shift.  at_out (optional): the block that was drawn
     template <typename Gen>
-    QcMatrix mutated(Gen &rnd) const {
+    QcMatrix mutated(Gen &rnd, size_t *at_out = nullptr) const {
         QcMatrix q = *this;
         const int i = (int) (rnd() % (unsigned) R);
         const int j = (int) (rnd() % (unsigned) C);
         const size_t at = (size_t) i * C + j;
         if (!q.present[at] || rnd() % 2 == 0) q.present[at] = !q.present[at];
         q.shift[at] = (int) (rnd() % (unsigned) Z);
+        if (at_out) *at_out = at;
         return q;
     }
 };
@@ -149,6 +153,16 @@ int main(int argc, char **argv) {
         std::printf("Z=%d R=%d C=%d\n", q.Z, q.R, q.C);
         for (int i = 0; i < q.R; i++) {
             for (int j = 0; j < q.C; j++) std::printf("%d%c", q.present[(size_t) i * q.C + j] ? q.shift[(size_t) i * q.C + j] : -1, j + 1 == q.C ? '\n' : ' ');
+        }
+        return 0;
+    }
+    if (a.has("--dump-proposals")) {  // host-only: the proposal sequence of optimize_H.cpp:89-104 without scoring
+        const int cnt = (int) a.integer("--dump-proposals", 16);
+        for (int it = 0; it < cnt; it++) {
+            size_t at = 0;
+            QcMatrix cand = q.mutated(rnd, &at);
+            std::printf("%d %d %d %d\n", (int) (at / (size_t) q.C), (int) (at % (size_t) q.C), (int) cand.present[at], cand.shift[at]);
+            if (a.has("--accept-all")) q = cand;
         }
         return 0;
     }

@@ -59,6 +59,44 @@ def main():
         del y, bits, ok, its
         return ms
 
+    def churn(gb):
+        t = torch.empty(gb << 30, dtype=torch.uint8, device="cuda")
+        t.fill_(1)
+        torch.cuda.synchronize()
+        del t
+        torch.cuda.empty_cache()
+
+    if len(sys.argv) > 1 and sys.argv[1] == "alloc":
+        # does a physically contiguous workspace (hipDeviceMallocContiguous) take the lottery out?
+        for mode in (0, 1, 0, 1):
+            os.environ["ACG_STREAM_WS_ALLOC"] = str(mode)
+            for k in range(3):
+                churn(48 if k % 2 == 0 else 16)
+                run("alloc_mode=%d after_churn_%d" % (mode, k), 3)
+                run("alloc_mode=%d recreate_%d" % (mode, k), 3)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "chunks":
+        # workspace made of separately created physical chunks mapped in a shuffled order (mode 2) / in creation order (mode 3)
+        for mode, mb in ((2, 2), (2, 32), (2, 256), (3, 32), (1, 0), (2, 32), (0, 0)):
+            os.environ["ACG_STREAM_WS_ALLOC"] = str(mode)
+            os.environ["ACG_STREAM_WS_CHUNK_MB"] = str(mb)
+            for k in range(2):
+                churn(48 if k % 2 == 0 else 16)
+                t0 = time.time()
+                run("mode=%d chunk=%dMB after_churn_%d" % (mode, mb, k), 3)
+                run("mode=%d chunk=%dMB recreate_%d (%.1fs)" % (mode, mb, k, time.time() - t0), 3)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "pads":
+        # slab stride sensitivity: for every pad, the decoder created right after a 48 GB allocate / free (the history that gave
+        # the slow mode) and created again straight away (the history that gave the fast one)
+        for pad in (0, 256, 3840, 4096 + 3840, 65536 + 3840, 2 * 1048576 - 10400000 % (2 * 1048576), 1 << 20):
+            os.environ["ACG_STREAM_SLAB_PAD"] = str(pad)
+            churn(48)
+            a = run("pad=%d after_free_48GB" % pad, 3)
+            b = run("pad=%d recreate" % pad, 3)
+            churn(16)
+            c = run("pad=%d after_free_16GB" % pad, 3)
+        return
     run("fresh")
     run("recreate_1")
     t = torch.empty(48 << 30, dtype=torch.uint8, device="cuda")
