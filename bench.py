@@ -57,7 +57,7 @@ CYC_VALU = 2.0
 CYC_TRANS = 8.0            # v_exp_f32 / v_log_f32 alone (quarter rate); the mul+exp PAIR measures 10-12
 CYC_VALU_F64 = 4.0         # fp64 add / mul / fma / max: half rate
 
-PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "qpadmm", "c5_block_ms", "c5_pair_f16_ms", "c5_streamed_ms")
+PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "ms_layered", "qpadmm", "c5_block_ms", "c5_pair_f16_ms", "c5_streamed_ms")
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
               ("write", ["WRITE_SIZE", "GRBM_GUI_ACTIVE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE",
@@ -562,9 +562,9 @@ def pmc_probe_child(a):
 
 PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
     "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 1),
-    "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true, true, 12, false>", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false>", 0),
-    "ms_streamed": ("bp_streamed_ring_kernel<1, false>", 0), "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
-    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true>", 0),
+    "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true, true, 12, false>", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false, false>", 0),
+    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2>", 0), "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
+    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true, false>", 0),
 }
 
 
@@ -990,7 +990,11 @@ def main():
                               "note": "min-sum is not in the reference: parity unpinned"}
         for key in ("ms_layered", "ms_layered_exit"):
             if key in T:   # layered schedule: half the sweeps, FER-level parity only
-                out["minsum_0.75"]["layered_fixed" if key == "ms_layered" else "layered_exit"] = decode_leg(rig, batch, T[key], a.snr, ss, 1)
+                r = decode_leg(rig, batch, T[key], a.snr, ss, 1)
+                if key == "ms_layered":
+                    c, src = pmc_lookup(pmc, "ms_layered")
+                    r["roofline"] = roofline_fused(c, src, r["kernel_ms"], F, bp_bytes_per_frame(n, E, a.iters // 2))
+                out["minsum_0.75"]["layered_fixed" if key == "ms_layered" else "layered_exit"] = r
         # ---- the HBM-resident engine: messages [edge][frame] in HBM, one lane per frame ------------------
         st = {}
         for key, item in (("sum_product", "bp_streamed"), ("minsum_0.75", "ms_streamed")):

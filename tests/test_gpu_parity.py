@@ -708,7 +708,9 @@ def test_config4_optimalh_qpadmm_snr_sweep_sharded(A, pcm):
 # ---------------------------------------------------------------------------------------- large parity sub-run, threads
 def test_bp_100k_frames_identical_to_oracle(A, oracle, matrices, pcm):
     """SURVEY §8(d) config-2 parity sub-run: 10^5 frames with the reference's host noise (frame i <- mt19937(i+1))
-    over SNR in {-3,-2,-1,0}: bits, flags and exit iterations identical to the oracle on every frame."""
+    over SNR in {-3,-2,-1,0}: bits and flags identical to the oracle on every frame; exit iterations identical except for the
+    stated fp32-vs-80-bit knife edge below (one sweep apart, same word, on at most 1 frame in 10^4 — exact exit-iteration parity
+    of the fp32 kernel was given up in round 2 for the one-instruction branch selection in phi, bp_core.inc)."""
     Hm, H = matrices["H05"], pcm["H05"]
     G, _ = H.get_orthogonal()
     cws = A.gen_random_codewords(G, 10000, 239239239)

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--qc", type=int, nargs=3, metavar=("MB", "NB", "Z"), default=None,
                     help="all-ones MB x NB protograph of Z x Z cyclic shifts (shift = (3r + 7c) mod Z): a structured code whose variable sweep "
                          "walks the message lines in a few sequential streams")
+    ap.add_argument("--layered", action="store_true", help="min-sum with the layered schedule (SCHEDULE_LAYERED)")
     ap.add_argument("--tag", default="")
     a = ap.parse_args()
     import numpy as np
@@ -63,7 +64,8 @@ def main():
     if a.algo == "qpadmm":
         dec = A.QPADMMDecoder(a.alpha, a.mu, a.iters, 1e-5 if a.exit else 0.0, lanes_per_frame=a.lanes, precision=prec)
     elif a.algo == "minsum":
-        dec = A.MinSumDecoder(a.iters, 0.75, early_exit=a.exit, lanes_per_frame=a.lanes, engine=eng, precision=prec)
+        dec = A.MinSumDecoder(a.iters, 0.75, early_exit=a.exit, lanes_per_frame=a.lanes, engine=eng, precision=prec,
+                              schedule=A.SCHEDULE_LAYERED if a.layered else A.SCHEDULE_FLOODING)
     else:
         dec = A.BeliefPropagationDecoder(a.iters, early_exit=a.exit, lanes_per_frame=a.lanes, engine=eng, precision=prec)
     h, _ = dec.handle(H)
