@@ -40,6 +40,17 @@ __device__ __forceinline__ u32 le0(u32 x) {
     const u32 nz = pk_min_u16(x & 0x7FFF7FFFu, LSB2);  // 1 where the magnitude is non-zero
     return ((x >> 15) & LSB2) | (nz ^ LSB2);
 }
+// the same predicate left in bit 15 of each half (other bits: garbage), in two instructions: as a 16-bit integer, x - 1 has
+// bit 15 set exactly for +0 (0x0000 - 1 = 0xFFFF) and for every negative value except -0 (0x8000 - 1 = 0x7FFF), whose own
+// sign bit the OR supplies; positive values (and positive NaNs) keep bit 15 clear in both terms.  Round 3: replaces
+// le0(x) << 15 (and, pk_min, shift, and, xor, or, shift) in the variable sweep — same bits, a third of the instructions.
+__device__ __forceinline__ u32 le0_bit15(u32 x) { return pk_sub_u16(x, LSB2) | x; }
+__device__ __forceinline__ u32 pk_sub_sat_u16(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ u32 pk_mad_u16(u32 a, u32 b, u32 c) {
+    return __builtin_bit_cast(u32, (us2) (__builtin_bit_cast(us2, a) * __builtin_bit_cast(us2, b) + __builtin_bit_cast(us2, c)));
+}
 
 // One check pass: D words at Ap[j*L] -> c->v words in place; returns the XOR word (LSB of each half = syndrome bit)
 template <int D, int L, bool UNIFORM>
@@ -61,13 +72,18 @@ __device__ __forceinline__ u32 pair_check(u32 *__restrict__ Ap, int slot, const 
         m1 = __builtin_elementwise_min(m1, aj);
         m2 = __builtin_elementwise_min(m2, t);
     }
-    const u32 u1 = as_u(m1), u2 = as_u(m2);
+    // Round 3: the two minima are scaled once per check instead of the selected one once per edge, and "m2 where this edge
+    // holds the minimum, else m1" is u1s + e * (u2s - u1s) with e = 1 - min(1, a_j ^ m1) per half: the magnitudes have their LSB
+    // clear, so a non-zero XOR is >= 2 and the saturating 1 - (a_j ^ m1) is exactly that e (one v_pk_sub_u16 clamp), and the
+    // select is one v_pk_mad_u16 — three instructions per edge where there were five (xor, min, sub, bfi, mul); same bits.
+    const u32 u1 = as_u(m1);
+    const u32 u1s = as_u(m1 * scale), u2s = as_u(m2 * scale);
+    const u32 dd = pk_sub_u16(u2s, u1s);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         // per half: the minimum over the OTHER edges = m2 where this edge holds the minimum, else m1
-        const u32 eq = pk_sub_u16(pk_min_u16(a[j] ^ u1, LSB2), LSB2);  // 0xFFFF where a_j == m1
-        const u32 o = (u2 & eq) | (u1 & ~eq);
-        const u32 sc = as_u(as_h2(o) * scale);
+        const u32 e = pk_sub_sat_u16(LSB2, a[j] ^ u1);  // 1 where a_j == m1, else 0
+        const u32 sc = pk_mad_u16(e, dd, u1s);
         const u32 ob = (sc & 0x7FFF7FFFu) | ((S ^ x[j]) & SIGN2);  // sign product, bp.h:54
         if (UNIFORM ? (slot < cnt[1]) : (slot < cnt[j + 1])) Ap[j * L] = ob;
     }
@@ -86,13 +102,13 @@ __device__ __forceinline__ u32 pair_var(u32 *__restrict__ A, const int (&pos)[D]
         pre[k] = s;
         s += c[k];
     }
-    const u32 hard = le0(as_u(llr + s));  // estimate() <= 0, bp.h:85-90,193
+    const u32 hard = (le0_bit15(as_u(llr + s)) >> 15) & LSB2;  // estimate() <= 0, bp.h:85-90,193
     h2 suf = as_h2(0u);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         const u32 xk = as_u(llr + (pre[k] + suf));  // bp.h:78-82
         suf += c[k];
-        const u32 ob = (xk & MAG2) | (le0(xk) << 15) | hard;
+        const u32 ob = (xk & MAG2) | ((le0_bit15(xk) & SIGN2) | hard);  // magnitude | sign (x <= 0 -> -1, bp.h:82) | hard-decision LSB
         if (slot < cnt[k + 1]) A[pos[k]] = ob;
     }
     return hard;
