@@ -38,7 +38,7 @@ const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, 
 const void *bp_kernel_ptr_dbg(int f64, int L);
 const void *bp_block_kernel_ptr_dbg(int f64);
 const void *bp_pair_kernel_ptr(int L, bool regular);
-const void *bp_layered_kernel_ptr(int G, int waves);
+const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16);
 hipError_t bp_layered_launch(const void *kernel, const LayerTables &t, const DecodeArgs &a, int grid, int block, size_t lds, hipStream_t s);
 const void *bp_streamed_ptr(int algo, int f64);
 const void *bp_streamed_ring_ptr(int algo, bool nt);
@@ -570,10 +570,11 @@ static int decoder_setup_layered(acg_ldpc_decoder *d) {
                   "and a layered schedule is a different algorithm (FER-level parity at best)");
         return 3;
     }
-    if (d->p.engine == ACG_LDPC_ENGINE_STREAMED || (d->p.precision != ACG_LDPC_PREC_DEFAULT && d->p.precision != ACG_LDPC_PREC_F32)) {
-        set_error("the layered schedule runs on the LDS-resident engine in fp32 only");
+    if (d->p.engine == ACG_LDPC_ENGINE_STREAMED || d->p.precision == ACG_LDPC_PREC_F64) {
+        set_error("the layered schedule runs on the LDS-resident engine with fp32 posteriors (messages fp32, or fp16 with ACG_LDPC_PREC_F16)");
         return 3;
     }
+    const bool lay_f16 = d->p.precision == ACG_LDPC_PREC_F16;
     if (!bp_layered_build(c, d->llay)) return 3;
     const LayeredLayout &ll = d->llay;
     if (d->p.lanes_per_frame != 0 && d->p.lanes_per_frame != ll.G) {
@@ -591,6 +592,11 @@ static int decoder_setup_layered(acg_ldpc_decoder *d) {
         d->dev_allocs.push_back(p32);
         t.proto = p32;
         t.pos = nullptr;
+        std::vector<int32_t> packed(ll.proto.size() / 2 + 8, 0);   // (+8: the kernel's scalar loads may run a few words ahead)
+        for (size_t k = 0; k + 1 < ll.proto.size(); k += 2) packed[k / 2] = (int32_t) (((uint32_t) (ll.proto[k] * ll.Z * 4) << 16) | (uint32_t) (ll.proto[k + 1] * 4));
+        if (upload<int32_t>(packed, &p32)) return 10;
+        d->dev_allocs.push_back(p32);
+        t.proto_packed = p32;
     } else {
         if (upload<uint16_t>(ll.pos, &p16)) return 10;
         d->dev_allocs.push_back(p16);
@@ -605,7 +611,8 @@ static int decoder_setup_layered(acg_ldpc_decoder *d) {
     t.p_words = (c.n + 1 + 3) & ~3;
     t.tab_lds_bytes = (int) (((size_t) ll.e_pad * 2 + 15) & ~(size_t) 15);
     // frame stride = G (mod 32) words: the lanes of the frames sharing a wavefront then fall into disjoint LDS banks
-    int words = t.p_words + t.e_pad + t.nwords;
+    t.r_words = lay_f16 ? (ll.e_pad + 1) / 2 : ll.e_pad;
+    int words = t.p_words + t.r_words + t.nwords;
     while (words % 32 != ll.G % 32) words++;
     t.lds_bytes_per_frame = words * 4;
     const int fpw = 64 / ll.G;
@@ -633,7 +640,10 @@ static int decoder_setup_layered(acg_ldpc_decoder *d) {
     d->block = waves * 64;
     d->frames_per_block = waves * fpw;
     d->lds_block = per_wave * waves + t.tab_lds_bytes;
-    const void *kp = bp_layered_kernel_ptr(ll.G, waves);
+    // positions by arithmetic in the hot loop when the block columns' byte offsets fit the packed word (n * 4 < 65536 holds: n < 16000)
+    // ACG_LAY_ARITH=1 (developer A/B): compute the positions of a quasi-cyclic H in the hot loop instead of reading the table
+    const bool qc_arith = ll.qc && ll.G == 20 && !lay_f16 && getenv("ACG_LAY_ARITH") != nullptr;
+    const void *kp = bp_layered_kernel_ptr(ll.G, waves, qc_arith, lay_f16);
     if (!kp) {
         set_error("no layered kernel instance for this group width");
         return 3;

@@ -42,21 +42,41 @@ __device__ __forceinline__ void lwave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// one layer step of degree D for this lane's check.  Pb: the frame's posteriors (byte-addressed), Rl / Tl: this lane's column
-// of the layer's messages / position table.  store: the lane owns a check of an active frame.
-// -> sign bit set <=> the step was not quiet for this lane
-template <int D, int G>
-__device__ __forceinline__ uint32_t layer_step(unsigned char *__restrict__ Pb, float *__restrict__ Rl, const uint16_t *__restrict__ Tl,
-                                               const bool store, const float scale) {
-    int pos[D];
+// A layer step is software-pipelined over the layers (occupancy is bounded by LDS — 4.6 KB per frame, 10 wavefronts per CU — so
+// registers are plentiful and latency is what there is to hide):
+//   fetch<D>   (issued during the PREVIOUS step) positions and old messages of this lane's check: they depend on the frame's
+//              previous iteration only, never on the layer before
+//   front<D>   posterior reads through the prefetched positions, Q = P - R
+//   ... the next layer's fetch is issued here, behind the posterior reads and ahead of the arithmetic ...
+//   back<D>    two minima, signs, R', P' — all 2 D stores under ONE predicate at the end (a predicate per edge costs an
+//              EXEC save / branch / restore each: 6 scalar instructions per edge in the first version, by the counters)
+constexpr int LMAXD = 8;
+// RT: storage type of the check-to-variable messages — float, or _Float16 (precision = ACG_LDPC_PREC_F16: 2.9 KB of LDS per
+// frame instead of 4.6, 16 wavefronts per CU instead of 10; the posteriors stay fp32 and always see the ROUNDED message, so the
+// iteration stays self-consistent: Q = P - R subtracts exactly what was added)
+template <int D, int G, typename RT>
+__device__ __forceinline__ void layer_fetch(const RT *__restrict__ Rl, const uint16_t *__restrict__ Tl, int (&pos)[LMAXD], float (&r)[LMAXD]) {
 #pragma unroll
     for (int j = 0; j < D; ++j) pos[j] = Tl[j * G];
-    float p[D], q[D], a[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) p[j] = *reinterpret_cast<const float *>(Pb + pos[j]);
+    for (int j = 0; j < D; ++j) r[j] = (float) Rl[j * G];
+}
+template <int D>
+__device__ __forceinline__ void layer_front(unsigned char *__restrict__ Pb, const int (&pos)[LMAXD], const float (&r)[LMAXD],
+                                            float *(&addr)[LMAXD], float (&p)[LMAXD], float (&q)[LMAXD]) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) q[j] = p[j] - Rl[j * G];
+    for (int j = 0; j < D; ++j) addr[j] = reinterpret_cast<float *>(Pb + pos[j]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) p[j] = *addr[j];
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] = p[j] - r[j];
+}
+// -> sign bit set <=> the step was not quiet for this lane
+template <int D, int G, typename RT>
+__device__ __forceinline__ uint32_t layer_back(RT *__restrict__ Rl, float *const (&addr)[LMAXD], const float (&p)[LMAXD], const float (&q)[LMAXD],
+                                               const bool store, const float scale) {
     uint32_t S = 0, noisy = 0;
+    float a[D];
     float m1 = INFINITY, m2 = INFINITY;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -66,19 +86,58 @@ __device__ __forceinline__ uint32_t layer_step(unsigned char *__restrict__ Pb, f
         m2 = __builtin_amdgcn_fmed3f(a[j], m1, m2);
         m1 = __builtin_fminf(m1, a[j]);
     }
-    const float m1s = scale * m1, m2s = scale * m2;
+    // the two minima are scaled once per check (made opaque: the compiler would otherwise turn select(s*m2, s*m1) back into
+    // s * select(m2, m1), one multiply per edge)
+    // (RT = _Float16: rounded to the storage type here, once per check, so that P' adds exactly what the next iteration subtracts)
+    uint32_t m1s = __float_as_uint((float) (RT) (scale * m1)) & 0x7FFFFFFFu, m2s = __float_as_uint((float) (RT) (scale * m2)) & 0x7FFFFFFFu;
+    asm volatile("" : "+v"(m1s), "+v"(m2s));
+    float rn[D], pn[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        const float mag = (a[j] == m1) ? m2s : m1s;         // a tie makes m2 == m1: either answer is the same
-        const float rn = __uint_as_float((__float_as_uint(mag) & 0x7FFFFFFFu) | ((S ^ __float_as_uint(q[j])) & 0x80000000u));
-        const float pn = q[j] + rn;
-        noisy |= __float_as_uint(pn) ^ __float_as_uint(p[j]);   // a hard decision flipped
-        if (store) {
-            *reinterpret_cast<float *>(Pb + pos[j]) = pn;
-            Rl[j * G] = rn;
-        }
+        const uint32_t mag = (a[j] == m1) ? m2s : m1s;      // a tie makes m2 == m1: either answer is the same
+        rn[j] = __uint_as_float(mag | ((S ^ __float_as_uint(q[j])) & 0x80000000u));
+        pn[j] = q[j] + rn[j];
+        noisy |= __float_as_uint(pn[j]) ^ __float_as_uint(p[j]);   // a hard decision flipped
+    }
+    if (store) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) *addr[j] = pn[j];
+#pragma unroll
+        for (int j = 0; j < D; ++j) Rl[j * G] = (RT) rn[j];   // (exact: the magnitude is already a value of RT)
     }
     return noisy;
+}
+
+// Posterior cells of a quasi-cyclic layer WITHOUT the table: variable = C_j * Z + (k + s_j) mod Z (optimize_H.cpp:41), all in
+// bytes: proto word j of the block row = C_j * Z * 4 << 16 | s_j * 4 (wave-uniform, scalar loads); k4 = 4 * (row of this lane in its
+// block row).  (k + s) mod Z as an unsigned minimum: k4 + s4 - 4 Z wraps to a huge number exactly when no reduction is due.
+// Four VALU instructions per edge in place of a ds_read_u16 and the LDS round trip it puts in front of the posterior reads.
+template <int D, int G, typename RT>
+__device__ __forceinline__ void layer_fetch_qc(const RT *__restrict__ Rl, const int32_t *proto_b, const int k4, const int z4,
+                                               int (&pos)[LMAXD], float (&r)[LMAXD]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) r[j] = (float) Rl[j * G];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const int w = lsload(proto_b, j);
+        const uint32_t tt = (uint32_t) (k4 + (w & 0xFFFF));
+        pos[j] = (int) (__builtin_elementwise_min(tt, tt - (uint32_t) z4) + ((uint32_t) w >> 16));
+    }
+}
+
+// one layer step: positions, posteriors, messages, arithmetic, stores.  QCA: positions by arithmetic (quasi-cyclic H), else
+// from the workgroup's table
+template <int D, int G, bool QCA, typename RT>
+__device__ __forceinline__ uint32_t layer_step(unsigned char *__restrict__ Pb, RT *__restrict__ Rl, const uint16_t *__restrict__ Tl,
+                                               const int32_t *proto_b, const int k4, const int z4, const bool store, const float scale) {
+    int pos[LMAXD];
+    float r[LMAXD];
+    if constexpr (QCA) layer_fetch_qc<D, G, RT>(Rl, proto_b, k4, z4, pos, r);
+    else layer_fetch<D, G, RT>(Rl, Tl, pos, r);
+    float *addr[LMAXD];
+    float p[LMAXD], q[LMAXD];
+    layer_front<D>(Pb, pos, r, addr, p, q);
+    return layer_back<D, G, RT>(Rl, addr, p, q, store, scale);
 }
 
 // parity of the posteriors' signs over this lane's check of a layer (explicit syndrome pass)
@@ -111,7 +170,9 @@ __device__ __forceinline__ bool lgroup_any(bool pred, int g) {
     return (b & mask) != 0ull;
 }
 
-template <int G, int WAVES>
+// QCA: the hot loop computes the posterior addresses of a quasi-cyclic H arithmetically (no table read); the table is still
+// built once per workgroup for the rare explicit syndrome pass.
+template <int G, int WAVES, bool QCA, typename RT>
 __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTables t, const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int FPW = 64 / G;
@@ -147,8 +208,8 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
     unsigned char *base = smem + t.tab_lds_bytes + (size_t) grp_in_block * t.lds_bytes_per_frame;
     unsigned char *Pb = base;                                             // P[n] + neutral cell (+ padding)
     float *P = reinterpret_cast<float *>(base);
-    float *R = P + t.p_words;
-    uint32_t *OB = reinterpret_cast<uint32_t *>(R + t.e_pad);
+    RT *R = reinterpret_cast<RT *>(P + t.p_words);
+    uint32_t *OB = reinterpret_cast<uint32_t *>(P + t.p_words + t.r_words);
     const float scale = a.ms_scale;
     const int NL = t.n_layers;
 
@@ -248,7 +309,7 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
                     P[v] = llr;
                 }
                 for (int w = t.n + l; w < t.p_words; w += G) P[w] = INFINITY;   // neutral cell: never the minimum, sign +
-                for (int w = l; w < t.e_pad; w += G) R[w] = 0.0f;
+                for (int w = l; w < t.e_pad; w += G) R[w] = (RT) 0.0f;
                 it = 0;
                 latched = false;
                 need_init = false;
@@ -258,11 +319,12 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
         // ---- one iteration: every layer in turn, posteriors updated in place ------------------------------------------------
         for (int b = 0; b < NL; ++b) {
             const int deg = lsload(t.layer, 4 * b), off = lsload(t.layer, 4 * b + 1), cnt = lsload(t.layer, 4 * b + 2);
-            float *Rl = R + off + l;
-            const uint16_t *Tl = TAB + off + l;
             const bool mine = active && l < cnt;
             uint32_t noisy = 0;
-#define ACG_CALL(D) noisy = layer_step<D, G>(Pb, Rl, Tl, mine, scale)
+            const int w3 = QCA ? lsload(t.layer, 4 * b + 3) : 0;
+            const int32_t *proto_b = t.proto_packed + (w3 & 0xFFFF);
+            const int k4 = 4 * ((w3 >> 16) + l);
+#define ACG_CALL(D) noisy = layer_step<D, G, QCA, RT>(Pb, R + off + l, TAB + off + l, proto_b, k4, 4 * t.Z, mine, scale)
             ACG_LAYER_SWITCH(deg, ACG_CALL)
 #undef ACG_CALL
             lwave_sync();
@@ -272,21 +334,24 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
     }
 }
 
-template <int G>
+template <int G, bool QCA, typename RT>
 static const void *layered_ptr_w(int waves) {
     switch (waves) {
-        case 1: return (const void *) bp_layered_kernel<G, 1>;
-        case 2: return (const void *) bp_layered_kernel<G, 2>;
-        default: return (const void *) bp_layered_kernel<G, 4>;
+        case 1: return (const void *) bp_layered_kernel<G, 1, QCA, RT>;
+        case 2: return (const void *) bp_layered_kernel<G, 2, QCA, RT>;
+        default: return (const void *) bp_layered_kernel<G, 4, QCA, RT>;
     }
 }
 
-const void *bp_layered_kernel_ptr(int G, int waves) {
+// qc_arith: positions computed in the hot loop instead of read from the table (G = 20, fp32 messages only: a measured
+// alternative, 14 % slower — DESIGN §3d); f16: messages stored in half precision
+const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16) {
+    if (qc_arith) return (G == 20 && !f16) ? layered_ptr_w<20, true, float>(waves) : nullptr;
     switch (G) {
-        case 16: return layered_ptr_w<16>(waves);
-        case 20: return layered_ptr_w<20>(waves);
-        case 32: return layered_ptr_w<32>(waves);
-        case 64: return layered_ptr_w<64>(waves);
+        case 16: return f16 ? layered_ptr_w<16, false, _Float16>(waves) : layered_ptr_w<16, false, float>(waves);
+        case 20: return f16 ? layered_ptr_w<20, false, _Float16>(waves) : layered_ptr_w<20, false, float>(waves);
+        case 32: return f16 ? layered_ptr_w<32, false, _Float16>(waves) : layered_ptr_w<32, false, float>(waves);
+        case 64: return f16 ? layered_ptr_w<64, false, _Float16>(waves) : layered_ptr_w<64, false, float>(waves);
         default: return nullptr;
     }
 }

@@ -60,10 +60,12 @@ struct DecodeArgs {
 struct LayerTables {
     const int32_t *layer;    // [n_layers][4] = {degree, message offset (words), checks, first proto entry | first row << 16}
     const int32_t *proto;    // quasi-cyclic H: {block column, shift} pairs per block row; null = use pos
+    const int32_t *proto_packed;  // the same, one word per pair: block column * Z * 4 << 16 | shift * 4 (byte units, for the hot loop)
     const uint16_t *pos;     // any other H: [e_pad] variable of (layer, edge, lane), n = neutral cell; null when proto is set
     int32_t n_layers, Z, n, nwords;
     int32_t e_pad;           // message words per frame
     int32_t p_words;         // posterior words per frame (n + the neutral cell, rounded up)
+    int32_t r_words;         // 32-bit words the e_pad messages of a frame occupy (e_pad, or half of it rounded up for fp16 storage)
     int32_t tab_lds_bytes;   // bytes of the workgroup's position table
     int32_t lds_bytes_per_frame;
 };

@@ -57,7 +57,7 @@ CYC_VALU = 2.0
 CYC_TRANS = 8.0            # v_exp_f32 / v_log_f32 alone (quarter rate); the mul+exp PAIR measures 10-12
 CYC_VALU_F64 = 4.0         # fp64 add / mul / fma / max: half rate
 
-PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "ms_layered", "qpadmm", "c5_block_ms", "c5_pair_f16_ms", "c5_streamed_ms")
+PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "ms_layered", "ms_layered_f16", "qpadmm", "c5_block_ms", "c5_pair_f16_ms", "c5_streamed_ms")
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
               ("write", ["WRITE_SIZE", "GRBM_GUI_ACTIVE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE",
@@ -499,6 +499,8 @@ def ctor_table(A, a):
         # layered schedule: half the iterations for the same FER — a different algorithm, FER-level parity only
         "ms_layered": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=False, device=dev, schedule=A.SCHEDULE_LAYERED),
         "ms_layered_exit": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=True, device=dev, schedule=A.SCHEDULE_LAYERED),
+        "ms_layered_f16": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=False, device=dev, schedule=A.SCHEDULE_LAYERED, precision=A.PREC_F16),
+        "ms_layered_f16_exit": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=True, device=dev, schedule=A.SCHEDULE_LAYERED, precision=A.PREC_F16),
         "qpadmm": lambda dev: A.QPADMMDecoder(a.alpha, a.mu, 100, 0.0, device=dev),          # eps 0: every frame runs 100 sweeps
         "qpadmm_exit": lambda dev: A.QPADMMDecoder(a.alpha, a.mu, 100, 1e-5, device=dev),
         "c5_block_ms": lambda dev: A.MinSumDecoder(50, 0.75, early_exit=False, device=dev),
@@ -563,7 +565,7 @@ def pmc_probe_child(a):
 PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
     "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 1),
     "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true, true, 12, false>", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false, false>", 0),
-    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2>", 0), "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
+    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float>", 0), "ms_layered_f16": ("bp_layered_kernel<20, 2, false, _Float16>", 0), "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
     "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true, false>", 0),
 }
 
@@ -820,7 +822,7 @@ def compact_line(d):
         if isinstance(v, dict) and "value" in v:
             legs["mc_" + k] = _triple(v)       # acg_ldpc_mc_run: SURVEY 8(d)'s definitional metric (noise + decode + D2H)
     ms = d.get("minsum_0.75") or {}
-    for k in ("fixed", "early_exit", "layered_fixed", "layered_exit"):
+    for k in ("fixed", "early_exit", "layered_fixed", "layered_exit", "layered_f16_fixed", "layered_f16_exit"):
         if ms.get(k):
             legs["minsum_" + k + " (parity unpinned)"] = _triple(ms[k])
     st = d.get("streamed") or {}
@@ -988,13 +990,14 @@ def main():
         out["minsum_0.75"] = {"fixed": decode_leg(rig, batch, T["ms_fused"], a.snr, ss, 1),
                               "early_exit": decode_leg(rig, batch, T["ms_exit"], a.snr, ss, 1),
                               "note": "min-sum is not in the reference: parity unpinned"}
-        for key in ("ms_layered", "ms_layered_exit"):
-            if key in T:   # layered schedule: half the sweeps, FER-level parity only
-                r = decode_leg(rig, batch, T[key], a.snr, ss, 1)
-                if key == "ms_layered":
-                    c, src = pmc_lookup(pmc, "ms_layered")
-                    r["roofline"] = roofline_fused(c, src, r["kernel_ms"], F, bp_bytes_per_frame(n, E, a.iters // 2))
-                out["minsum_0.75"]["layered_fixed" if key == "ms_layered" else "layered_exit"] = r
+        for key, name in (("ms_layered", "layered_fixed"), ("ms_layered_exit", "layered_exit"), ("ms_layered_f16", "layered_f16_fixed"),
+                          ("ms_layered_f16_exit", "layered_f16_exit")):
+            # layered schedule: half the sweeps for the same FER, FER-level parity only; f16 = messages stored in half precision
+            r = decode_leg(rig, batch, T[key], a.snr, ss, 1)
+            if key in ("ms_layered", "ms_layered_f16"):
+                c, src = pmc_lookup(pmc, key)
+                r["roofline"] = roofline_fused(c, src, r["kernel_ms"], F, bp_bytes_per_frame(n, E, a.iters // 2, b=4 if key == "ms_layered" else 2))
+            out["minsum_0.75"][name] = r
         # ---- the HBM-resident engine: messages [edge][frame] in HBM, one lane per frame ------------------
         st = {}
         for key, item in (("sum_product", "bp_streamed"), ("minsum_0.75", "ms_streamed")):

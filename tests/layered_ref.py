@@ -5,8 +5,10 @@ FER-level only (tests/test_layered.py)."""
 import numpy as np
 
 
-def layered_minsum(Hm, layers, y, snr, max_iter, scale):
+def layered_minsum(Hm, layers, y, snr, max_iter, scale, msg_dtype=np.float32):
     """Hm: m x n 0/1; layers: [n_layers, G] check ids (-1 = none) in processing order; y: frames x n float64 symbols.
+    msg_dtype: storage type of the check-to-variable messages (np.float16 = precision PREC_F16: the scaled minima are rounded
+    to half precision once per check; the posteriors stay fp32 and add / subtract exactly the rounded message).
     -> bits [F, n] uint8 (zeros for failed frames), ok [F] uint8, iters [F] int32"""
     Hm = np.asarray(Hm)
     F, n = y.shape
@@ -34,7 +36,9 @@ def layered_minsum(Hm, layers, y, snr, max_iter, scale):
                 a = np.abs(q)
                 srt = np.sort(a, axis=1)
                 m1, m2 = srt[:, 0], (srt[:, 1] if a.shape[1] > 1 else np.full(F, np.inf, np.float32))
-                m1s, m2s = scale * m1, scale * m2
+                with np.errstate(over="ignore"):
+                    m1s = (scale * m1).astype(msg_dtype).astype(np.float32)
+                    m2s = (scale * m2).astype(msg_dtype).astype(np.float32)
                 mag = np.where(a == m1[:, None], m2s[:, None], m1s[:, None]).astype(np.float32)
                 sq = np.signbit(q)
                 S = np.logical_xor.reduce(sq, axis=1)

@@ -77,10 +77,12 @@ def A():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("msg", ["f32", "f16"])
 @pytest.mark.parametrize("name,snr", [("H05", -2.0), ("H05", 0.5), ("optimalH", -2.0), ("H", 1.0)])
-def test_layered_kernel_equals_restatement(A, oracle, matrices, name, snr):
+def test_layered_kernel_equals_restatement(A, oracle, matrices, name, snr, msg):
     """words, flags and iteration counts identical to the numpy restatement (the repo's own: parity unpinned), with the
-    reference's stopping semantics and in fixed-work mode, for 25, 3 and 0 iterations"""
+    reference's stopping semantics and in fixed-work mode, for 25, 3 and 0 iterations; messages stored in fp32 or (precision
+    PREC_F16) in half precision"""
     Hm = matrices[name]
     H = A.ParityCheckMatrix(Hm)
     G, _ = oracle.get_orthogonal(Hm)
@@ -88,9 +90,10 @@ def test_layered_kernel_equals_restatement(A, oracle, matrices, name, snr):
     y = oracle.transmit_frames(cws, snr, first_seed=1)
     _, _, layers = H.layers()
     for it in (25, 3, 0):
-        rb, rok, rit = layered_minsum(Hm, layers, y, snr, it, 0.75)
+        rb, rok, rit = layered_minsum(Hm, layers, y, snr, it, 0.75, np.float16 if msg == "f16" else np.float32)
         for ee in (True, False):
-            dec = A.MinSumDecoder(it, 0.75, schedule=A.SCHEDULE_LAYERED, early_exit=ee)
+            dec = A.MinSumDecoder(it, 0.75, schedule=A.SCHEDULE_LAYERED, early_exit=ee,
+                                  precision=A.PREC_F16 if msg == "f16" else A.PREC_DEFAULT)
             bits, ok, iters = dec.decode_batch(H, y, snr)
             assert "bp_layered_kernel" in dec.describe(H) and "layered" in dec.describe(H)
             dec.close()
@@ -130,11 +133,22 @@ def test_layered_refuses_what_it_is_not(A, matrices):
         A.MinSumDecoder(10, 0.75, schedule=A.SCHEDULE_LAYERED, engine=A.ENGINE_STREAMED).decode_batch(H, y, 0.0)
     with pytest.raises(A.LdpcError):
         A.MinSumDecoder(10, 0.75, schedule=A.SCHEDULE_LAYERED, precision=A.PREC_F64).decode_batch(H, y, 0.0)
+    # the arithmetic-addressing instance (developer A/B switch) gives the same words as the table-driven one
+    import os
+    yy = np.random.default_rng(1).normal(1.0, 0.9, size=(300, 280))
+    ref = A.MinSumDecoder(12, 0.75, schedule=A.SCHEDULE_LAYERED).decode_batch(H, yy, -1.0)
+    os.environ["ACG_LAY_ARITH"] = "1"
+    try:
+        got = A.MinSumDecoder(12, 0.75, schedule=A.SCHEDULE_LAYERED).decode_batch(H, yy, -1.0)
+    finally:
+        del os.environ["ACG_LAY_ARITH"]
+    assert all((a == b).all() for a, b in zip(ref, got))
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f16"])
 @pytest.mark.parametrize("name", ["H05", "optimalH"])
-def test_layered_25_not_worse_than_flooding_50(A, matrices, name):
+def test_layered_25_not_worse_than_flooding_50(A, matrices, name, prec):
     """>= 2^20 device-noise frames per point: FER(layered min-sum, 25 iterations) <= FER(flooding min-sum, 50) + binomial
     slack, at -2 and -1 dB; every ok = 1 word is a codeword (pseudo-codewords are counted by the classification kernel,
     which recomputes the syndrome); the sum-product FER of the reference's own algorithm is printed beside them"""
@@ -143,7 +157,7 @@ def test_layered_25_not_worse_than_flooding_50(A, matrices, name):
     cws = A.gen_random_codewords(G, 4096, 239239239)
     F = 1 << 20
     for snr in (-2.0, -1.0):
-        lay = A.MinSumDecoder(25, 0.75, schedule=A.SCHEDULE_LAYERED)
+        lay = A.MinSumDecoder(25, 0.75, schedule=A.SCHEDULE_LAYERED, precision=A.PREC_F16 if prec == "f16" else A.PREC_DEFAULT)
         flo = A.MinSumDecoder(50, 0.75)
         spa = A.BeliefPropagationDecoder(50)
         rl = A.run_experiment(lay, cws, H, snr, frames=F, noise="device", seed=3)
@@ -154,8 +168,8 @@ def test_layered_25_not_worse_than_flooding_50(A, matrices, name):
         assert rl.total == rf.total == F and rl.sum_hamming == rf.sum_hamming      # the same frames
         fl, ff = rl.FER(), rf.FER()
         slack = 4.0 * np.sqrt(max(ff * (1 - ff), 1e-6) / F) * np.sqrt(2)
-        print("%s %+.1f dB: FER layered-25 %.5f  flooding-50 %.5f  sum-product-50 %.5f; mean iterations %.2f / %.2f / %.2f; pseudo %d / %d"
-              % (name, snr, fl, ff, rs.FER(), rl.mean_iters(), rf.mean_iters(), rs.mean_iters(), rl.pseudo, rf.pseudo))
+        print("%s %s %+.1f dB: FER layered-25 %.5f  flooding-50 %.5f  sum-product-50 %.5f; mean iterations %.2f / %.2f / %.2f; pseudo %d / %d"
+              % (name, prec, snr, fl, ff, rs.FER(), rl.mean_iters(), rf.mean_iters(), rs.mean_iters(), rl.pseudo, rf.pseudo))
         assert fl <= ff + slack, (name, snr, fl, ff)
         # fewer sweeps: about half while a frame is still moving, plus the one quiet round that proves convergence
         assert rl.mean_iters() < 0.85 * rf.mean_iters()
