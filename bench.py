@@ -565,7 +565,7 @@ def pmc_probe_child(a):
 PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
     "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 1),
     "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true, true, 12, false>", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false, false>", 0),
-    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float>", 0), "ms_layered_f16": ("bp_layered_kernel<20, 2, false, _Float16>", 0), "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
+    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float>", 0), "ms_layered_f16": (("bp_layered_kernel<20, 4, false, _Float16>", "bp_layered_kernelILi20ELi4ELb0EDF16_"), 0),   # (rocprofv3 leaves _Float16 mangled) "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
     "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true, false>", 0),
 }
 
@@ -611,7 +611,7 @@ def pmc_one_pass(a, tag, ctrs, left, env, out):
                 except (KeyError, ValueError):
                     pass
         for item, (pat, pos) in PROBE_KERNEL.items():
-            ks = [k for k in per if pat in k]
+            ks = [k for k in per if any(q in k for q in ((pat,) if isinstance(pat, str) else pat))]
             if not ks:
                 continue
             disp = sorted(per[ks[0]].items())
@@ -655,7 +655,7 @@ def pmc_collect(a, budget_s):
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import valu_mix
-        mix = valu_mix.static_mix({item: pat for item, (pat, _) in PROBE_KERNEL.items()})
+        mix = valu_mix.static_mix({item: (pat if isinstance(pat, str) else pat[0]) for item, (pat, _) in PROBE_KERNEL.items()})
         for item, m in mix.items():
             out["items"][item].update({"STATIC_VALU_FULL_RATE": m["full_rate"], "STATIC_VALU_HALF_RATE": m["half_rate"],
                                        "STATIC_VALU_TRANS": m["transcendental"],
