@@ -51,6 +51,7 @@ __device__ __forceinline__ void lwave_sync() {
 //   back<D>    two minima, signs, R', P' — all 2 D stores under ONE predicate at the end (a predicate per edge costs an
 //              EXEC save / branch / restore each: 6 scalar instructions per edge in the first version, by the counters)
 constexpr int LMAXD = 8;
+constexpr float LAYERED_SATURATION = 59968.0f;   // message of a one-variable check ("certainly 0"); representable in fp16
 // RT: storage type of the check-to-variable messages — float, or _Float16 (precision = ACG_LDPC_PREC_F16: 2.9 KB of LDS per
 // frame instead of 4.6, 16 wavefronts per CU instead of 10; the posteriors stay fp32 and always see the ROUNDED message, so the
 // iteration stays self-consistent: Q = P - R subtracts exactly what was added)
@@ -90,6 +91,9 @@ __device__ __forceinline__ uint32_t layer_back(RT *__restrict__ Rl, float *const
     // s * select(m2, m1), one multiply per edge)
     // (RT = _Float16: rounded to the storage type here, once per check, so that P' adds exactly what the next iteration subtracts)
     uint32_t m1s = __float_as_uint((float) (RT) (scale * m1)) & 0x7FFFFFFFu, m2s = __float_as_uint((float) (RT) (scale * m2)) & 0x7FFFFFFFu;
+    // a check with ONE variable pins it to 0: the minimum over its (empty) set of other edges is +inf, and an infinite message
+    // would turn the next Q = P - R into inf - inf.  It saturates at a value far above any real message instead (exact in fp16).
+    if constexpr (D == 1) m2s = __float_as_uint((float) (RT) LAYERED_SATURATION);
     asm volatile("" : "+v"(m1s), "+v"(m2s));
     float rn[D], pn[D];
 #pragma unroll

@@ -36,9 +36,13 @@ def layered_minsum(Hm, layers, y, snr, max_iter, scale, msg_dtype=np.float32):
                 a = np.abs(q)
                 srt = np.sort(a, axis=1)
                 m1, m2 = srt[:, 0], (srt[:, 1] if a.shape[1] > 1 else np.full(F, np.inf, np.float32))
+                # the kernel forms scale * min and rounds it to the storage type in ONE step (v_fma_mixlo_f16 for fp16): the
+                # product of two fp32 numbers is exact in float64, so rounding that once is the same thing
                 with np.errstate(over="ignore"):
-                    m1s = (scale * m1).astype(msg_dtype).astype(np.float32)
-                    m2s = (scale * m2).astype(msg_dtype).astype(np.float32)
+                    m1s = (np.float64(scale) * m1.astype(np.float64)).astype(msg_dtype).astype(np.float32)
+                    m2s = (np.float64(scale) * m2.astype(np.float64)).astype(msg_dtype).astype(np.float32)
+                if a.shape[1] == 1:       # a one-variable check: its message saturates instead of being infinite
+                    m2s = np.full(F, np.float32(59968.0), dtype=np.float32)
                 mag = np.where(a == m1[:, None], m2s[:, None], m1s[:, None]).astype(np.float32)
                 sq = np.signbit(q)
                 S = np.logical_xor.reduce(sq, axis=1)

@@ -124,6 +124,28 @@ def test_layered_ragged_batches_and_float_symbols(A, oracle, matrices):
 
 
 @pytest.mark.gpu
+def test_layered_ragged_graph(A, oracle):
+    """a matrix that is neither quasi-cyclic nor regular: an empty check, a degree-3 check among degree-6 ones, isolated
+    variables, a degree-1 check — greedy-coloured layers of several degrees with partly filled lanes"""
+    Hm = A.regular_ldpc(40, 80, 3, 6, seed=5).copy()
+    Hm[0, :] = 0
+    Hm[1, np.nonzero(Hm[1])[0][:3]] = 0
+    Hm[2, np.nonzero(Hm[2])[0][1:]] = 0          # degree 1
+    Hm[:, 7] = 0                                  # an isolated variable
+    H = A.ParityCheckMatrix(Hm)
+    G, Z, layers = H.layers()
+    assert Z == 0 and len(set(Hm[l[l >= 0]].sum(axis=1)[0] for l in layers)) >= 3
+    y = oracle.transmit_frames(np.zeros((400, 80), dtype=np.uint8), 1.0, first_seed=9)
+    for prec, dt in ((A.PREC_DEFAULT, np.float32), (A.PREC_F16, np.float16)):
+        rb, rok, rit = layered_minsum(Hm, layers, y, 1.0, 15, 0.8, dt)
+        dec = A.MinSumDecoder(15, 0.8, schedule=A.SCHEDULE_LAYERED, precision=prec)
+        bits, ok, iters = dec.decode_batch(H, y, 1.0)
+        dec.close()
+        assert (ok == rok).all() and (bits == rb).all() and (iters == rit).all()
+        assert 0 < ok.sum() < len(ok) or ok.all()
+
+
+@pytest.mark.gpu
 def test_layered_refuses_what_it_is_not(A, matrices):
     H = A.ParityCheckMatrix(matrices["H05"])
     y = np.ones((1, 280))
