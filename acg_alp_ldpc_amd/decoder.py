@@ -13,7 +13,9 @@
 Every call runs on the GPU through libacg_ldpc_hip.so; there is no CPU path.
 """
 import collections
+import contextlib
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -42,6 +44,8 @@ class Decoder:
         self.fast_setup = bool(fast_setup)
         self.max_handles = int(max_handles) if max_handles else self.MAX_HANDLES
         self._handles = collections.OrderedDict()  # analysed-graph cache keyed on H (SURVEY §8b "Inputs"), LRU order
+        self._pins = collections.Counter()         # calls in flight per key: a handle in use is never evicted
+        self._lock = threading.RLock()             # (ctypes calls release the GIL: one decoder object may be used from threads)
 
     # -- parameters -------------------------------------------------------------------------
     def _params(self):
@@ -71,7 +75,12 @@ class Decoder:
         return ("dense", a.shape, np.packbits(a != 0).tobytes())
 
     def handle(self, H):
-        k = self._key(H)
+        """(device handle, ParityCheckMatrix) for H — valid until max_handles OTHER matrices have been used through this object;
+        the decode calls below pin theirs for the duration of the call."""
+        with self._lock:
+            return self._lookup(self._key(H), H)
+
+    def _lookup(self, k, H):
         ent = self._handles.get(k)
         if ent is not None:
             self._handles.move_to_end(k)
@@ -82,18 +91,42 @@ class Decoder:
         check(lib().acg_ldpc_decoder_create(code._h, C.byref(p), C.byref(h)))
         ent = (h, code)
         self._handles[k] = ent
-        while len(self._handles) > self.max_handles:
-            _, (old, _) = self._handles.popitem(last=False)
-            lib().acg_ldpc_decoder_destroy(old)   # synchronises the handle's stream first
+        self._trim()
         return ent
+
+    def _trim(self):
+        if len(self._handles) <= self.max_handles:
+            return
+        for k in list(self._handles):           # least recently used first; never the newest, never one in use
+            if len(self._handles) <= self.max_handles:
+                break
+            if self._pins[k] == 0 and k != next(reversed(self._handles)):
+                old, _ = self._handles.pop(k)
+                lib().acg_ldpc_decoder_destroy(old)   # synchronises the handle's stream first
+
+    @contextlib.contextmanager
+    def _lease(self, H):
+        """the handle for H, kept out of the eviction's reach while a call uses it"""
+        with self._lock:
+            k = self._key(H)
+            ent = self._lookup(k, H)
+            self._pins[k] += 1
+        try:
+            yield ent
+        finally:
+            with self._lock:
+                self._pins[k] -= 1
+                self._trim()
 
     def live_handles(self):
         return len(self._handles)
 
     def close(self):
-        for h, _ in self._handles.values():
-            lib().acg_ldpc_decoder_destroy(h)
-        self._handles = collections.OrderedDict()
+        with self._lock:
+            for h, _ in self._handles.values():
+                lib().acg_ldpc_decoder_destroy(h)
+            self._handles = collections.OrderedDict()
+            self._pins.clear()
 
     def __del__(self):
         try:
@@ -114,7 +147,10 @@ class Decoder:
     def decode_batch(self, H, Y, snr, out=None):
         """Y: frames x n channel symbols.  float64 (default): the reference's exact LLRs; a float32 array travels as
         float32 (half the PCIe bytes, acg_ldpc_decode_batch_f32).  out = (bits, ok, iters) reuses caller arrays."""
-        h, code = self.handle(H)
+        with self._lease(H) as (h, code):
+            return self._decode_batch(h, code, Y, snr, out)
+
+    def _decode_batch(self, h, code, Y, snr, out):
         f32 = isinstance(Y, np.ndarray) and Y.dtype == np.float32
         Y = np.ascontiguousarray(Y, dtype=np.float32 if f32 else np.float64)
         if Y.ndim != 2 or Y.shape[1] != code.n:
@@ -134,9 +170,9 @@ class Decoder:
 
     def decode_batch_dev(self, H, y_ptr, y_is_f64, frames, snr, bits_ptr, ok_ptr, iters_ptr=None, stream=None):
         """device pointers (ints); asynchronous on `stream` (None = the decoder's own stream)"""
-        h, _ = self.handle(H)
-        check(lib().acg_ldpc_decode_batch_dev(h, y_ptr, 1 if y_is_f64 else 0, int(frames), float(snr), bits_ptr,
-                                              ok_ptr, iters_ptr, stream))
+        with self._lease(H) as (h, _):
+            check(lib().acg_ldpc_decode_batch_dev(h, y_ptr, 1 if y_is_f64 else 0, int(frames), float(snr), bits_ptr,
+                                                  ok_ptr, iters_ptr, stream))
 
     def sync(self, H):
         h, _ = self.handle(H)

@@ -74,6 +74,39 @@ def test_one_decoder_64_matrices_bounded_handles(oracle, algo):
 
 
 @pytest.mark.gpu
+def test_one_decoder_many_matrices_from_threads():
+    """4 host threads, 12 distinct H, ONE decoder object with room for 8 handles (ctypes calls release the GIL): a handle in use
+    by one thread is pinned, never destroyed under it; every result equals the single-threaded one"""
+    import threading
+    import acg_alp_ldpc_amd as A
+    rng = np.random.default_rng(3)
+    mats = [A.regular_ldpc(48, 96, 3, 6, seed=500 + s) for s in range(12)]
+    ys = [rng.normal(1.0, 0.7, size=(64, 96)) for _ in mats]
+    ref = A.BeliefPropagationDecoder(15)
+    want = [ref.decode_batch(Hm, y, 1.0) for Hm, y in zip(mats, ys)]
+    ref.close()
+    dec = A.BeliefPropagationDecoder(15)
+    errs = []
+
+    def work(t):
+        try:
+            for rep in range(6):
+                for s in range(t, 12, 4) if rep % 2 == 0 else range(12):
+                    got = dec.decode_batch(mats[s], ys[s], 1.0)
+                    assert all((a == b).all() for a, b in zip(got, want[s])), (t, rep, s)
+                    assert dec.live_handles() <= dec.max_handles + 4
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[0]
+    assert dec.live_handles() <= dec.max_handles
+    dec.close()
+
+
+@pytest.mark.gpu
 def test_cxx_adaptor_100_matrices_bounded(tmp_path):
     """the C++ mirror (include/acg_ldpc_decoder.hpp): 100 distinct H through one BeliefPropagationDecoder and one
     QPADMMDecoder, from 4 host threads at once"""
