@@ -620,6 +620,30 @@ def test_config5_block_kernel_variants_agree_near_threshold(A, oracle):
     assert (ok == ook).all() and (bits == ob).all() and (iters == oit).all()
 
 
+def test_bp_fp32_knife_edge_frames(A, oracle, matrices, pcm):
+    """The three frames of 4 * 10^6 (tools/soak_oracle.py, H05, BP-50, -2 / -1 dB; fixture tests/golden/bp_knife_edges.npz: symbols +
+    the restatement's outputs) on which the fp32 kernels reach the zero syndrome ONE sweep apart from the 80-bit restatement: the
+    word and the flag are the oracle's, the exit iteration differs by exactly one — the stated tolerance of the fp32 engines, pinned
+    (fp64 messages reproduce the oracle's iteration too)."""
+    k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bp_knife_edges.npz"))
+    Hm, H = matrices["H05"], pcm["H05"]
+    for i in range(len(k["snr"])):
+        snr, y = float(k["snr"][i]), np.ascontiguousarray(k["y"][i:i + 1])
+        want = np.unpackbits(k["oracle_bits"][i])[:H.n]
+        ob, ook, oit = oracle.bp_decode(Hm, y, snr, 50)           # the fixture is what the oracle says today
+        assert (ob[0] == want).all() and ook[0] == k["oracle_ok"][i] and oit[0] == k["oracle_iters"][i]
+        for eng in (A.ENGINE_FUSED, A.ENGINE_STREAMED):
+            dec = A.BeliefPropagationDecoder(50, engine=eng)
+            bits, ok, iters = dec.decode_batch(H, y, snr)
+            dec.close()
+            assert (bits[0] == want).all() and ok[0] == ook[0] == 1
+            assert abs(int(iters[0]) - int(oit[0])) == 1, (i, eng, iters[0], oit[0])
+        d64 = A.BeliefPropagationDecoder(50, precision=A.PREC_F64)
+        bits, ok, iters = d64.decode_batch(H, y, snr)
+        d64.close()
+        assert (bits[0] == want).all() and ok[0] == 1 and iters[0] == oit[0]
+
+
 @pytest.mark.parametrize("engine", ["streamed_ring", "streamed_regs", "fused", "fused_block256"])
 @pytest.mark.parametrize("name", MATS)
 @pytest.mark.parametrize("snr", [-2.0, 2.0])

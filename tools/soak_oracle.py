@@ -11,7 +11,10 @@ from oracle.pyoracle import Oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=1000000)
 ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--bp-only", action="store_true", help="fused BP only (faster): used to collect the knife-edge frames")
+ap.add_argument("--dump-knife-edges", default=None, help="npz: every frame whose exit iteration differs from the restatement's (y, oracle and GPU outputs)")
 a = ap.parse_args()
+knife = {"snr": [], "y": [], "oracle_bits": [], "oracle_ok": [], "oracle_iters": [], "gpu_iters": []}
 o = Oracle()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 Hm = o.read_pcm(os.path.join(ROOT, "data", "H05.txt"))
@@ -34,9 +37,13 @@ for snr in (-2.0, -1.0):
         ob, ook, oit = o.bp_decode(Hm, y, snr, 50, threads=a.threads)
         bits, ok, iters = bp.decode_batch(H, y, snr)
         nb += int((bits != ob).any(axis=1).sum()); nk += int((ok != ook).sum()); ni += int((iters != oit).sum())
-        bits, ok, iters = bs.decode_batch(H, y, snr)
-        nbs += int((bits != ob).any(axis=1).sum()); nks += int((ok != ook).sum()); nis += int((iters != oit).sum())
-        if done < a.frames // 5:  # QP-ADMM restatement is slower: a fifth of the frames
+        for i in np.nonzero(iters != oit)[0]:
+            knife["snr"].append(snr); knife["y"].append(y[i]); knife["oracle_bits"].append(ob[i]); knife["oracle_ok"].append(ook[i])
+            knife["oracle_iters"].append(oit[i]); knife["gpu_iters"].append(iters[i])
+        if not a.bp_only:
+            bits, ok, iters = bs.decode_batch(H, y, snr)
+            nbs += int((bits != ob).any(axis=1).sum()); nks += int((ok != ook).sum()); nis += int((iters != oit).sum())
+        if done < a.frames // 5 and not a.bp_only:  # QP-ADMM restatement is slower: a fifth of the frames
             ob, ook, oit = o.qpadmm_decode(Hm, y, snr, 1.95, 0.5, 100, 1e-5, threads=a.threads)
             bits, ok, iters = ad.decode_batch(H, y, snr)
             nb += int((bits != ob).any(axis=1).sum()); nk += int((ok != ook).sum()); ni += int((iters != oit).sum())
@@ -44,4 +51,7 @@ for snr in (-2.0, -1.0):
         print("snr %+.1f: %d frames, fused BP + QP-ADMM: mismatching words %d flags %d iterations %d | streamed ring BP: words %d flags %d iterations %d (%.0f s)"
               % (snr, done, nb, nk, ni, nbs, nks, nis, time.time() - t0), flush=True)
     bad += nb + nk + nbs + nks   # (exit iterations of the fp32 kernels may differ by one on ~1e-6 of the frames: reported, not failed)
+if a.dump_knife_edges and knife["y"]:
+    np.savez_compressed(a.dump_knife_edges, **{k: np.array(v) for k, v in knife.items()})
+    print("knife-edge frames: %d -> %s" % (len(knife["y"]), a.dump_knife_edges))
 sys.exit(1 if bad else 0)
