@@ -171,11 +171,41 @@ static double time_ms(F launch, int reps) {
     return ms / reps;
 }
 
+// round 3: where the slabs live decides the rate once they exceed the Infinity Cache: 0 = hipMalloc (fast or slow per
+// allocation), 1 = hipDeviceMallocContiguous (the slow mode), 2 = 64 MiB physical chunks mapped into one virtual range (what the
+// streamed engine uses now)
+static float *alloc_slabs(size_t bytes, int mode) {
+    void *p = nullptr;
+    if (mode == 1) {
+        CHECK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous));
+    } else if (mode == 2) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        const size_t chunk = (size_t) 64 << 20, n = (bytes + chunk - 1) / chunk;
+        CHECK(hipMemAddressReserve(&p, n * chunk, 0, nullptr, 0));
+        for (size_t i = 0; i < n; i++) {
+            hipMemGenericAllocationHandle_t h;
+            CHECK(hipMemCreate(&h, chunk, &prop, 0));
+            CHECK(hipMemMap((char *) p + i * chunk, chunk, 0, h, 0));
+        }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        CHECK(hipMemSetAccess(p, n * chunk, &acc, 1));
+    } else {
+        CHECK(hipMalloc(&p, bytes));
+    }
+    return (float *) p;
+}
+
 int main(int argc, char **argv) {
     const int blocks = argc > 1 ? atoi(argv[1]) : 512, lines = argc > 2 ? atoi(argv[2]) : 1140, sweeps = argc > 3 ? atoi(argv[3]) : 50;
-    float *slabs = nullptr;
+    const int amode = argc > 4 ? atoi(argv[4]) : 0;
     const size_t words = (size_t) blocks * lines * 64;
-    CHECK(hipMalloc(&slabs, words * 4));
+    float *slabs = alloc_slabs(words * 4, amode);
+    printf("allocation: %s\n", amode == 1 ? "hipDeviceMallocContiguous" : (amode == 2 ? "64 MiB chunks mapped into one range (hipMemCreate / hipMemMap)" : "hipMalloc"));
     CHECK(hipMemset(slabs, 0, words * 4));
     const double bytes = 2.0 * words * 4 * sweeps;  // read + write
     printf("%d workgroups x %d lines x 256 B = %.0f MB of slabs, %d sweeps, %.1f GB moved per launch\n", blocks, lines, words * 4 / 1e6,
@@ -210,8 +240,7 @@ int main(int argc, char **argv) {
     RUN_WIDE(8)
     RUN_WIDE(16)
     RUN_WIDE(32)
-    float *slabs2 = nullptr;
-    CHECK(hipMalloc(&slabs2, words * 4));
+    float *slabs2 = alloc_slabs(words * 4, amode);
     CHECK(hipMemset(slabs2, 0, words * 4));
 #define RUN_PP(P, NT, IP)                                                                                         \
     {                                                                                                             \
@@ -224,7 +253,5 @@ int main(int argc, char **argv) {
     RUN_PP(16, false, false)
     RUN_PP(16, true, true)
     RUN_PP(16, true, false)
-    CHECK(hipFree(slabs2));
-    CHECK(hipFree(slabs));
-    return 0;
+    return 0;  // (the process ends here: the allocations go with it)
 }
