@@ -239,10 +239,11 @@ private:
     int _max_iter;
 };
 
-// build-added (north_star); not in the reference
+// build-added (north_star); not in the reference: parity unpinned.  layered = true: ACG_LDPC_SCHEDULE_LAYERED (about half the
+// iterations for the same FER; FER-level parity only)
 class MinSumDecoder : public HipDecoderBase {
 public:
-    explicit MinSumDecoder(int max_iter, double scale = 1.0) : _max_iter(max_iter), _scale(scale) {}
+    explicit MinSumDecoder(int max_iter, double scale = 1.0, bool layered = false) : _max_iter(max_iter), _scale(scale), _layered(layered) {}
     std::string name() const override { return "MS"; }
 
 protected:
@@ -250,6 +251,7 @@ protected:
         p.algo = ACG_LDPC_BP_MINSUM;
         p.max_iter = _max_iter;
         p.ms_scale = _scale;
+        p.schedule = _layered ? ACG_LDPC_SCHEDULE_LAYERED : ACG_LDPC_SCHEDULE_FLOODING;
     }
     std::pair<TCodeword, bool> finish(const std::vector<uint8_t> &bits, bool ok) const override {
         if (!ok) return {TCodeword(), false};
@@ -259,6 +261,7 @@ protected:
 private:
     int _max_iter;
     double _scale;
+    bool _layered;
 };
 
 }  // namespace acg_ldpc

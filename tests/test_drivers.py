@@ -107,6 +107,33 @@ def test_eval_driver_reproduces_reference_known_answers(drivers, tmp_path):
 
 
 @pytest.mark.gpu
+def test_eval_driver_minsum_rows(drivers, oracle, tmp_path):
+    """the optional min-sum rows of acg_eval (build-added variant, parity unpinned): with the reference's host-noise frames the FER
+    of the layered decoder equals what the repo's numpy restatement gets on the same 1000 frames, and the flooding row's FER is
+    the oracle min-sum's"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from layered_ref import layered_minsum
+    import acg_alp_ldpc_amd as A
+    Hm = oracle.read_pcm(os.path.join(DATA, "H05.txt"))
+    G, _ = oracle.get_orthogonal(Hm)
+    cws = oracle.gen_codewords(G, 239239239, 1000)
+    y = oracle.transmit_frames(cws, -2.0, first_seed=1)
+    _, _, layers = A.ParityCheckMatrix(Hm).layers()
+    rb, rok, _ = layered_minsum(Hm, layers, y, -2.0, 25, 0.75)
+    fer_lay = 1 - ((rok == 1) & (rb == cws).all(axis=1)).mean()
+    ob, ook, _ = oracle.minsum_decode(Hm, y, -2.0, 50, 0.75)
+    fer_flo = 1 - ((ook == 1) & (ob == cws).all(axis=1)).mean()
+    for extra, want in ((["--minsum-iters", "25", "--layered"], fer_lay), (["--minsum-iters", "50"], fer_flo)):
+        csv = str(tmp_path / "r.csv")
+        r = subprocess.run([os.path.join(drivers, "acg_eval"), "--H", os.path.join(DATA, "H05.txt"), "--snrs", "-2", "--tests", "1000", "--noise", "host",
+                            "--no-bp", "--no-admm", "--out", csv] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        row = open(csv).read().strip().split("\n")[1].split(",")
+        assert row[0] == "MS" and abs(float(row[3]) - want) < 1e-9, (extra, row, want)
+
+
+@pytest.mark.gpu
 def test_grid_search_driver_matches_oracle(drivers, oracle):
     """qpadmm_params.cpp loop on a 3 x 3 sub-grid, 200 frames: every FER and the winner equal the oracle's"""
     H = oracle.read_pcm(os.path.join(DATA, "optimalH.txt"))

@@ -4,6 +4,8 @@
 //   acg_eval --H data/optimalH.txt [--G data/G05.txt] [--snrs -5,-4.5,...,0] [--tests 10000] [--bp-iters 100]
 //            [--alpha 1.2 --mu 0.55 --admm-iters 10000 --eps 1e-5] [--noise host|device] [--seed 1] [--out report.csv]
 //            [--gpus N]   (one decoder handle + host thread per GPU, contiguous frame ranges, counters summed)
+//            [--minsum-iters N [--ms-scale 0.75] [--layered] [--ms-f16]]   also evaluate the build-added normalised min-sum
+//                         (NOT in the reference: parity unpinned), flooding or with the layered schedule
 // Defaults are main.cpp's (OPTIMAL build): optimalH, BP(100), QP-ADMM(1.2, 0.55, 10000, 1e-5), 10000 codewords from
 // mt19937(239'239'239), SNRs -5..0 step 0.5.  --noise host reproduces the reference's frames bit for bit
 // (frame i <- mt19937(i+1)); --noise device keeps generation, decoding and classification on the GPU.
@@ -50,6 +52,17 @@ int main(int argc, char **argv) {
         p.mu = a.num("--mu", 0.55);
         p.max_iter = (int) a.integer("--admm-iters", 10000);
         p.eps_stop = a.num("--eps", 1e-5);
+        decs.emplace_back();
+        decs.back().create(code, p, gpus, ndev);
+    }
+
+    if (a.has("--minsum-iters")) {  // build-added variant (north_star); not one of main.cpp's decoders
+        acg_ldpc_params_default(&p);
+        p.algo = ACG_LDPC_BP_MINSUM;
+        p.max_iter = (int) a.integer("--minsum-iters", 50);
+        p.ms_scale = a.num("--ms-scale", 0.75);
+        if (a.has("--layered")) p.schedule = ACG_LDPC_SCHEDULE_LAYERED;
+        if (a.has("--ms-f16")) p.precision = ACG_LDPC_PREC_F16;
         decs.emplace_back();
         decs.back().create(code, p, gpus, ndev);
     }
