@@ -314,6 +314,7 @@ struct acg_ldpc_decoder {
     bool sring_nt = false;  // ring instance with non-temporal slab accesses (slabs beyond the Infinity Cache)
     uint32_t *sws = nullptr;
     ScatteredAlloc sws_scattered;  // backing of sws when it was made of shuffled physical chunks (else sws is a hipMalloc)
+    std::vector<float> sws_probe_ms;  // probe time of every workspace candidate that was tried (the fastest was kept)
     int sgrid = 0;
     // ADMM
     AdmmDevice *admm = nullptr;
@@ -532,15 +533,19 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
     }
     {
         // Where the slabs live decides the rate of the ring kernel once they exceed the Infinity Cache (configs[4]: 768 slabs of
-        // 10.4 MB; tools/stream_bimodal.py, profiles/r03_stream_bimodal.txt, one process, same kernel instance, same virtual address):
-        //   hipMalloc                             158 ms or 181 ms per launch, fixed for the life of the allocation, decided anew by
-        //                                         every hipMalloc (this is round 2's "158 or 179 ms depending on the box")
-        //   hipDeviceMallocContiguous             181 ms, 12 of 12 allocations: the slow mode IS the physically contiguous backing
-        //   physical chunks mapped into one       149 ms, 20 of 20, chunk size 2 / 32 / 256 MiB, shuffled or in creation order
-        //   virtual range (hipMemCreate/hipMemMap)
-        // The slab stride does not matter in any of them.  So the workspace is built from 64 MiB chunks (shuffled with a fixed
-        // seed); plain hipMalloc remains the fallback and the small-workspace path.  ACG_STREAM_WS_ALLOC = 0 / 1 / 2 / 3 forces
-        // hipMalloc / contiguous / shuffled chunks / chunks in creation order (developer A/B only).
+        // 10.4 MB; tools/stream_bimodal.py, profiles/r03_stream_bimodal.txt: one process, same kernel instance, same virtual
+        // address, a new allocation per measurement, three GPU boxes):
+        //   hipDeviceMallocContiguous             181 ms per launch, every time, whatever the slab stride: a physically contiguous
+        //                                         backing is the slowest one
+        //   hipMalloc                             158 or 181 ms, fixed for the life of the allocation, decided anew by every
+        //                                         hipMalloc (round 2's "158 or 179 ms depending on the box"); one box gave 180 only
+        //   physical chunks mapped into one       149-153 ms on one box (20 of 20), 152-180 ms (mostly 157-169) on another: never
+        //   virtual range (hipMemCreate/hipMemMap) worse than hipMalloc, but still a draw per allocation
+        // What the draw is (the physical placement the driver hands out) cannot be seen or steered from user space, but it can be
+        // MEASURED: so a large workspace is allocated ACG_STREAM_WS_TRIES (default 3) times from 64 MiB chunks, each candidate is
+        // timed with a three-sweep launch of the decoder's own kernel over one tile per resident workgroup (about 10 ms), and the
+        // fastest is kept.  hipMalloc remains the fallback and the small-workspace path.  ACG_STREAM_WS_ALLOC = 0 / 1 / 2 / 3
+        // forces hipMalloc / contiguous / shuffled chunks / chunks in creation order (developer A/B only).
         const char *wa = getenv("ACG_STREAM_WS_ALLOC");
         const int mode = wa ? atoi(wa) : (ws_bytes >= ((size_t) 64 << 20) ? 2 : 0);
         hipError_t e = hipErrorUnknown;
@@ -548,7 +553,51 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
         if (mode >= 2) {
             const char *cm = getenv("ACG_STREAM_WS_CHUNK_MB");
             const size_t chunk = (size_t) (cm ? atol(cm) : 64) << 20;
-            if (d->sws_scattered.create(ws_bytes, chunk, d->device, mode == 2)) {
+            const char *tr = getenv("ACG_STREAM_WS_TRIES");
+            int tries = tr ? atoi(tr) : 3;
+            // the draw only matters beyond the Infinity Cache, and the probe needs the ring kernel and room for its symbols
+            const int64_t probe_frames = (int64_t) d->sgrid * 64;
+            if (!d->sring || ws_bytes <= ((size_t) 512 << 20) || (size_t) probe_frames * c.n * 4 > ws_bytes) tries = 1;
+            tries = std::max(1, std::min(tries, 6));
+            std::vector<ScatteredAlloc> cand((size_t) tries);
+            int best = -1;
+            float best_ms = 0;
+            d->sws_probe_ms.clear();
+            for (int k = 0; k < tries; k++) {
+                if (!cand[k].create(ws_bytes, chunk, d->device, mode == 2)) break;
+                float ms = 0;
+                if (tries > 1) {
+                    DecodeArgs pa{};
+                    pa.y = cand[k].va;           // any readable memory will do as symbols: the probe times traffic, not decoding
+                    pa.y_is_f64 = 0;
+                    pa.frames = probe_frames;
+                    pa.inv_var2 = 1.0;
+                    pa.var = 1.0;
+                    pa.max_iter = 3;
+                    pa.early_exit = 0;
+                    pa.ms_scale = 0.75f;
+                    pa.work_counter = d->work_ring;
+                    bool okp = true;
+                    for (int rep = 0; rep < 2 && okp; rep++) {   // the second launch is the one timed
+                        okp = hipMemsetAsync(d->work_ring, 0, sizeof(unsigned long long), d->stream) == hipSuccess &&
+                              hipEventRecord(d->ring_ev0[0], d->stream) == hipSuccess &&
+                              bp_streamed_ring_launch(d->sring, d->stab, pa, (uint32_t *) cand[k].va, d->sgrid, d->stream) == hipSuccess &&
+                              hipEventRecord(d->ring_ev[0], d->stream) == hipSuccess && hipStreamSynchronize(d->stream) == hipSuccess;
+                    }
+                    if (!okp || hipEventElapsedTime(&ms, d->ring_ev0[0], d->ring_ev[0]) != hipSuccess) ms = 1e30f;
+                    d->sws_probe_ms.push_back(ms);
+                }
+                if (best < 0 || ms < best_ms) {
+                    best = k;
+                    best_ms = ms;
+                }
+            }
+            (void) hipGetLastError();
+            for (int k = 0; k < tries; k++)
+                if (k != best) cand[k].release();
+            if (best >= 0) {
+                d->sws_scattered = std::move(cand[best]);
+                cand[best].va = nullptr;
                 d->sws = (uint32_t *) d->sws_scattered.va;
                 e = hipSuccess;
             }
@@ -1027,6 +1076,16 @@ static std::string describe(const acg_ldpc_decoder *d) {
                  algo, d->sring ? "bp_streamed_ring_kernel" : "bp_streamed_kernel", d->sring ? (d->sring_nt ? "<NT>" : "<default-policy>") : "",
                  d->f64, slab, d->sgrid, slab * (size_t) d->sgrid, (void *) d->sws, d->sring ? d->sring_per_cu : 2,
                  d->sws_scattered.va ? "flooding workspace=mapped-chunks" : "flooding workspace=hipMalloc");
+        if (!d->sws_probe_ms.empty()) {
+            std::string t = b;
+            t += " workspace_probe_ms=";
+            for (size_t i = 0; i < d->sws_probe_ms.size(); i++) {
+                char q[32];
+                snprintf(q, sizeof q, "%s%.2f", i ? "/" : "", d->sws_probe_ms[i]);
+                t += q;
+            }
+            return t;
+        }
     } else {
         snprintf(b, sizeof b, "%s engine=fused kernel=%s lanes_per_frame=%d f64=%d block=%d frames_per_block=%d lds_block=%zu grid_cap=%d "
                                "idx_lds=%d idx_reg=%d schedule=%s",

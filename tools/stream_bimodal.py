@@ -53,8 +53,10 @@ def main():
             torch.cuda.synchronize()
             if k:
                 ms.append(e0.elapsed_time(e1))
-        print("%-28s base=%#x  mod2MiB=%#8x mod1GiB=%#10x  ms=%s  ok=%d" % (tag, base, base % (2 << 20), base % (1 << 30),
-                                                                           " ".join("%.1f" % x for x in ms), int(ok.sum())), flush=True)
+        probe = re.search(r"workspace_probe_ms=(\S+)", desc)
+        print("%-28s base=%#x  mod2MiB=%#8x mod1GiB=%#10x  ms=%s  ok=%d%s" % (tag, base, base % (2 << 20), base % (1 << 30),
+                                                                             " ".join("%.1f" % x for x in ms), int(ok.sum()),
+                                                                             ("  probes of the candidates (ms): " + probe.group(1)) if probe else ""), flush=True)
         dec.close()
         del y, bits, ok, its
         return ms
@@ -74,6 +76,24 @@ def main():
                 churn(48 if k % 2 == 0 else 16)
                 run("alloc_mode=%d after_churn_%d" % (mode, k), 3)
                 run("alloc_mode=%d recreate_%d" % (mode, k), 3)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "tries":
+        # best-of-K workspace candidates (what the library does by default, K = 3) against K = 1, alternating
+        for rep in range(4):
+            for k in (1, 3, 5):
+                os.environ["ACG_STREAM_WS_TRIES"] = str(k)
+                churn(16 if rep % 2 else 48)
+                run("tries=%d rep %d" % (k, rep), 3)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "contig_pads":
+        # a physically contiguous workspace has a DETERMINISTIC layout: is there a slab stride that makes it fast?
+        os.environ["ACG_STREAM_WS_ALLOC"] = "1"
+        base = 10400000
+        for pad in (0, 256, 1024, 2048, 3840, 4096 + 3840, 16384 - base % 16384, 65536 - base % 65536, 65536 - base % 65536 + 256,
+                    (1 << 20) - base % (1 << 20), (1 << 20) - base % (1 << 20) + 4096, (2 << 20) - base % (2 << 20), (2 << 20) - base % (2 << 20) + 256,
+                    (2 << 20) - base % (2 << 20) + 65536, 777 * 256, 12345 * 256):
+            os.environ["ACG_STREAM_SLAB_PAD"] = str(pad)
+            run("contiguous stride=%d (+%d)" % (base + pad, pad), 2)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "chunks":
         # workspace made of separately created physical chunks mapped in a shuffled order (mode 2) / in creation order (mode 3)
