@@ -565,8 +565,9 @@ def pmc_probe_child(a):
 PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
     "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 1),
     "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true, true, 12, false>", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false, false>", 0),
-    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float>", 0), "ms_layered_f16": (("bp_layered_kernel<20, 4, false, _Float16>", "bp_layered_kernelILi20ELi4ELb0EDF16_"), 0),   # (rocprofv3 leaves _Float16 mangled) "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
-    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true, false>", 0),
+    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float>", 0), "ms_layered_f16": (("bp_layered_kernel<20, 4, false, _Float16>", "bp_layered_kernelILi20ELi4ELb0EDF16_"), 0),   # (rocprofv3 leaves _Float16 mangled)
+    "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
+    "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true, false>", -1),   # (-1: the last two dispatches — the workspace probes launch this kernel too)
 }
 
 
@@ -615,7 +616,7 @@ def pmc_one_pass(a, tag, ctrs, left, env, out):
             if not ks:
                 continue
             disp = sorted(per[ks[0]].items())
-            mine = disp[2 * pos:2 * pos + 2]
+            mine = disp[-2:] if pos < 0 else disp[2 * pos:2 * pos + 2]
             for c in ctrs:
                 vals = [d[c] for _, d in mine if c in d]
                 if vals:

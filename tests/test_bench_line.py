@@ -96,6 +96,15 @@ def test_roofline_frac_is_the_guaranteed_figure():
     assert h["bound"] == "hbm" and 0.6 < h["frac"] < 0.7
 
 
+def test_every_probed_item_has_a_kernel_pattern():
+    """(round 3 lost the QP-ADMM counters for two runs to a comment in the middle of the table)"""
+    import bench
+    assert set(bench.PROBE_KERNEL) == set(bench.PROBE_ITEMS)
+    for item, (pat, pos) in bench.PROBE_KERNEL.items():
+        assert (isinstance(pat, str) and pat) or (isinstance(pat, tuple) and all(pat)), item
+        assert isinstance(pos, int)
+
+
 def test_usable_cores_reads_affinity_not_cpu_count(monkeypatch):
     import bench
     monkeypatch.setattr(os, "cpu_count", lambda: 256)
