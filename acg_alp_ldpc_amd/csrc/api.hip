@@ -38,7 +38,7 @@ const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, 
 const void *bp_kernel_ptr_dbg(int f64, int L);
 const void *bp_block_kernel_ptr_dbg(int f64);
 const void *bp_pair_kernel_ptr(int L, bool regular);
-const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16);
+const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16, int algo);
 hipError_t bp_layered_launch(const void *kernel, const LayerTables &t, const DecodeArgs &a, int grid, int block, size_t lds, hipStream_t s);
 const void *bp_streamed_ptr(int algo, int f64);
 const void *bp_streamed_ring_ptr(int algo, bool nt);
@@ -614,11 +614,8 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
 // schedule = LAYERED: min-sum over conflict-free layers of checks with in-place posteriors (bp_layered.hip)
 static int decoder_setup_layered(acg_ldpc_decoder *d) {
     const Code &c = d->c;
-    if (d->p.algo != ACG_LDPC_BP_MINSUM) {
-        set_error("ACG_LDPC_SCHEDULE_LAYERED exists for the min-sum decoder only: the reference's sum-product BP floods (bp.h:183-199) "
-                  "and a layered schedule is a different algorithm (FER-level parity at best)");
-        return 3;
-    }
+    // (sum-product with the layered schedule is the reference's check rule, bp.h:49-57, in another message order: a different
+    // algorithm from BeliefPropagationDecoder — FER-level parity only — that the caller has to ask for explicitly)
     if (d->p.engine == ACG_LDPC_ENGINE_STREAMED || d->p.precision == ACG_LDPC_PREC_F64) {
         set_error("the layered schedule runs on the LDS-resident engine with fp32 posteriors (messages fp32, or fp16 with ACG_LDPC_PREC_F16)");
         return 3;
@@ -691,8 +688,9 @@ static int decoder_setup_layered(acg_ldpc_decoder *d) {
     d->lds_block = per_wave * waves + t.tab_lds_bytes;
     // positions by arithmetic in the hot loop when the block columns' byte offsets fit the packed word (n * 4 < 65536 holds: n < 16000)
     // ACG_LAY_ARITH=1 (developer A/B): compute the positions of a quasi-cyclic H in the hot loop instead of reading the table
-    const bool qc_arith = ll.qc && ll.G == 20 && !lay_f16 && getenv("ACG_LAY_ARITH") != nullptr;
-    const void *kp = bp_layered_kernel_ptr(ll.G, waves, qc_arith, lay_f16);
+    const int lay_algo = d->p.algo == ACG_LDPC_BP_MINSUM ? 1 : 0;
+    const bool qc_arith = ll.qc && ll.G == 20 && !lay_f16 && lay_algo == 1 && getenv("ACG_LAY_ARITH") != nullptr;
+    const void *kp = bp_layered_kernel_ptr(ll.G, waves, qc_arith, lay_f16, lay_algo);
     if (!kp) {
         set_error("no layered kernel instance for this group width");
         return 3;

@@ -32,6 +32,7 @@
 #include "kernels.hpp"
 
 namespace acg {
+#include "bp_core.inc"   // Dom<float>::phi (the fp32 phi of the flooding kernels, log2(e)-scaled domain) for the sum-product variant
 
 typedef const int32_t __attribute__((address_space(4))) *lsconst_i32;
 __device__ __forceinline__ int lsload(const int32_t *p, int i) { return ((lsconst_i32) (p))[i]; }
@@ -112,6 +113,46 @@ __device__ __forceinline__ uint32_t layer_back(RT *__restrict__ Rl, float *const
     return noisy;
 }
 
+// The same step for SUM-PRODUCT (ALGO = 0; the reference's check rule, bp.h:49-57, in the layered schedule): magnitudes through
+// phi, exclude-self sums by prefix / suffix (never total - own: an infinite term would turn into NaN), phi again — two phi per
+// edge and iteration, as in the flooding kernels, but about half the iterations.  The posteriors and messages live in the
+// log2(e)-scaled domain of Dom<float>.  A message saturates at LAYERED_SPA_SATURATION (57.7 in natural units, far beyond the
+// reference's own saturation of phi at 45.7): an infinite message would turn the next P - R into inf - inf.
+constexpr float LAYERED_SPA_SATURATION = 83.25f;
+template <int D, int G, typename RT>
+__device__ __forceinline__ uint32_t layer_back_spa(RT *__restrict__ Rl, float *const (&addr)[LMAXD], const float (&p)[LMAXD], const float (&q)[LMAXD],
+                                                   const bool store) {
+    uint32_t S = 0, noisy = 0;
+    float mag[D], pre[D];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        noisy ^= __float_as_uint(p[j]);                     // parity of the hard decisions this check sees
+        S ^= __float_as_uint(q[j]);
+        mag[j] = Dom<float>::phi(__uint_as_float(__float_as_uint(q[j]) & 0x7FFFFFFFu));
+        pre[j] = s;
+        s += mag[j];
+    }
+    float rn[D], pn[D];
+    float suf = 0.0f;
+#pragma unroll
+    for (int j = D - 1; j >= 0; --j) {
+        float out = __builtin_fminf(Dom<float>::phi(pre[j] + suf), LAYERED_SPA_SATURATION);
+        suf += mag[j];
+        out = (float) (RT) out;                              // (fp16 storage: P' adds exactly what the next iteration subtracts)
+        rn[j] = __uint_as_float((__float_as_uint(out) & 0x7FFFFFFFu) | ((S ^ __float_as_uint(q[j])) & 0x80000000u));
+        pn[j] = q[j] + rn[j];
+        noisy |= __float_as_uint(pn[j]) ^ __float_as_uint(p[j]);
+    }
+    if (store) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) *addr[j] = pn[j];
+#pragma unroll
+        for (int j = 0; j < D; ++j) Rl[j * G] = (RT) rn[j];
+    }
+    return noisy;
+}
+
 // Posterior cells of a quasi-cyclic layer WITHOUT the table: variable = C_j * Z + (k + s_j) mod Z (optimize_H.cpp:41), all in
 // bytes: proto word j of the block row = C_j * Z * 4 << 16 | s_j * 4 (wave-uniform, scalar loads); k4 = 4 * (row of this lane in its
 // block row).  (k + s) mod Z as an unsigned minimum: k4 + s4 - 4 Z wraps to a huge number exactly when no reduction is due.
@@ -131,7 +172,7 @@ __device__ __forceinline__ void layer_fetch_qc(const RT *__restrict__ Rl, const 
 
 // one layer step: positions, posteriors, messages, arithmetic, stores.  QCA: positions by arithmetic (quasi-cyclic H), else
 // from the workgroup's table
-template <int D, int G, bool QCA, typename RT>
+template <int D, int G, bool QCA, typename RT, int ALGO>
 __device__ __forceinline__ uint32_t layer_step(unsigned char *__restrict__ Pb, RT *__restrict__ Rl, const uint16_t *__restrict__ Tl,
                                                const int32_t *proto_b, const int k4, const int z4, const bool store, const float scale) {
     int pos[LMAXD];
@@ -141,7 +182,8 @@ __device__ __forceinline__ uint32_t layer_step(unsigned char *__restrict__ Pb, R
     float *addr[LMAXD];
     float p[LMAXD], q[LMAXD];
     layer_front<D>(Pb, pos, r, addr, p, q);
-    return layer_back<D, G, RT>(Rl, addr, p, q, store, scale);
+    if constexpr (ALGO == 0) return layer_back_spa<D, G, RT>(Rl, addr, p, q, store);
+    else return layer_back<D, G, RT>(Rl, addr, p, q, store, scale);
 }
 
 // parity of the posteriors' signs over this lane's check of a layer (explicit syndrome pass)
@@ -176,7 +218,8 @@ __device__ __forceinline__ bool lgroup_any(bool pred, int g) {
 
 // QCA: the hot loop computes the posterior addresses of a quasi-cyclic H arithmetically (no table read); the table is still
 // built once per workgroup for the rare explicit syndrome pass.
-template <int G, int WAVES, bool QCA, typename RT>
+// ALGO: 1 = normalised min-sum, 0 = sum-product (phi domain)
+template <int G, int WAVES, bool QCA, typename RT, int ALGO>
 __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTables t, const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int FPW = 64 / G;
@@ -310,7 +353,7 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
                     float llr;
                     if (a.y_is_f64) llr = (float) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + v] / a.var);
                     else llr = (float) ((double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + v] * a.inv_var2);
-                    P[v] = llr;
+                    P[v] = (ALGO == 0) ? llr * (float) Dom<float>::scale : llr;
                 }
                 for (int w = t.n + l; w < t.p_words; w += G) P[w] = INFINITY;   // neutral cell: never the minimum, sign +
                 for (int w = l; w < t.e_pad; w += G) R[w] = (RT) 0.0f;
@@ -328,7 +371,7 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
             const int w3 = QCA ? lsload(t.layer, 4 * b + 3) : 0;
             const int32_t *proto_b = t.proto_packed + (w3 & 0xFFFF);
             const int k4 = 4 * ((w3 >> 16) + l);
-#define ACG_CALL(D) noisy = layer_step<D, G, QCA, RT>(Pb, R + off + l, TAB + off + l, proto_b, k4, 4 * t.Z, mine, scale)
+#define ACG_CALL(D) noisy = layer_step<D, G, QCA, RT, ALGO>(Pb, R + off + l, TAB + off + l, proto_b, k4, 4 * t.Z, mine, scale)
             ACG_LAYER_SWITCH(deg, ACG_CALL)
 #undef ACG_CALL
             lwave_sync();
@@ -338,24 +381,29 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
     }
 }
 
-template <int G, bool QCA, typename RT>
+template <int G, bool QCA, typename RT, int ALGO>
 static const void *layered_ptr_w(int waves) {
     switch (waves) {
-        case 1: return (const void *) bp_layered_kernel<G, 1, QCA, RT>;
-        case 2: return (const void *) bp_layered_kernel<G, 2, QCA, RT>;
-        default: return (const void *) bp_layered_kernel<G, 4, QCA, RT>;
+        case 1: return (const void *) bp_layered_kernel<G, 1, QCA, RT, ALGO>;
+        case 2: return (const void *) bp_layered_kernel<G, 2, QCA, RT, ALGO>;
+        default: return (const void *) bp_layered_kernel<G, 4, QCA, RT, ALGO>;
     }
 }
+template <int G>
+static const void *layered_ptr_g(int waves, bool f16, int algo) {
+    if (algo == 0) return f16 ? layered_ptr_w<G, false, _Float16, 0>(waves) : layered_ptr_w<G, false, float, 0>(waves);
+    return f16 ? layered_ptr_w<G, false, _Float16, 1>(waves) : layered_ptr_w<G, false, float, 1>(waves);
+}
 
-// qc_arith: positions computed in the hot loop instead of read from the table (G = 20, fp32 messages only: a measured
-// alternative, 14 % slower — DESIGN §3d); f16: messages stored in half precision
-const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16) {
-    if (qc_arith) return (G == 20 && !f16) ? layered_ptr_w<20, true, float>(waves) : nullptr;
+// algo: 0 sum-product, 1 min-sum.  qc_arith: positions computed in the hot loop instead of read from the table (G = 20, fp32
+// min-sum only: a measured alternative, 14 % slower — DESIGN §3d); f16: messages stored in half precision
+const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16, int algo) {
+    if (qc_arith) return (G == 20 && !f16 && algo == 1) ? layered_ptr_w<20, true, float, 1>(waves) : nullptr;
     switch (G) {
-        case 16: return f16 ? layered_ptr_w<16, false, _Float16>(waves) : layered_ptr_w<16, false, float>(waves);
-        case 20: return f16 ? layered_ptr_w<20, false, _Float16>(waves) : layered_ptr_w<20, false, float>(waves);
-        case 32: return f16 ? layered_ptr_w<32, false, _Float16>(waves) : layered_ptr_w<32, false, float>(waves);
-        case 64: return f16 ? layered_ptr_w<64, false, _Float16>(waves) : layered_ptr_w<64, false, float>(waves);
+        case 16: return layered_ptr_g<16>(waves, f16, algo);
+        case 20: return layered_ptr_g<20>(waves, f16, algo);
+        case 32: return layered_ptr_g<32>(waves, f16, algo);
+        case 64: return layered_ptr_g<64>(waves, f16, algo);
         default: return nullptr;
     }
 }

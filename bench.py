@@ -57,7 +57,7 @@ CYC_VALU = 2.0
 CYC_TRANS = 8.0            # v_exp_f32 / v_log_f32 alone (quarter rate); the mul+exp PAIR measures 10-12
 CYC_VALU_F64 = 4.0         # fp64 add / mul / fma / max: half rate
 
-PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "ms_layered", "ms_layered_f16", "qpadmm", "c5_block_ms", "c5_pair_f16_ms", "c5_streamed_ms")
+PROBE_ITEMS = ("bp_fused", "bp_exit", "bp_mc", "bp_streamed", "ms_streamed", "ms_layered", "ms_layered_f16", "bp_layered", "qpadmm", "c5_block_ms", "c5_pair_f16_ms", "c5_streamed_ms")
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]),
               ("write", ["WRITE_SIZE", "GRBM_GUI_ACTIVE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE",
@@ -499,6 +499,10 @@ def ctor_table(A, a):
         # layered schedule: half the iterations for the same FER — a different algorithm, FER-level parity only
         "ms_layered": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=False, device=dev, schedule=A.SCHEDULE_LAYERED),
         "ms_layered_exit": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=True, device=dev, schedule=A.SCHEDULE_LAYERED),
+        # the reference's sum-product check rule in the layered order: its FER at half its iterations (FER-level parity only)
+        "bp_layered": lambda dev: A.BeliefPropagationDecoder(a.iters // 2, early_exit=False, device=dev, schedule=A.SCHEDULE_LAYERED),
+        "bp_layered_exit": lambda dev: A.BeliefPropagationDecoder(a.iters // 2, early_exit=True, device=dev, schedule=A.SCHEDULE_LAYERED),
+        "bp_layered_f16_exit": lambda dev: A.BeliefPropagationDecoder(a.iters // 2, early_exit=True, device=dev, schedule=A.SCHEDULE_LAYERED, precision=A.PREC_F16),
         "ms_layered_f16": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=False, device=dev, schedule=A.SCHEDULE_LAYERED, precision=A.PREC_F16),
         "ms_layered_f16_exit": lambda dev: A.MinSumDecoder(a.iters // 2, 0.75, early_exit=True, device=dev, schedule=A.SCHEDULE_LAYERED, precision=A.PREC_F16),
         "qpadmm": lambda dev: A.QPADMMDecoder(a.alpha, a.mu, 100, 0.0, device=dev),          # eps 0: every frame runs 100 sweeps
@@ -565,7 +569,8 @@ def pmc_probe_child(a):
 PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
     "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 1),
     "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true, true, 12, false>", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false, false>", 0),
-    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float>", 0), "ms_layered_f16": (("bp_layered_kernel<20, 4, false, _Float16>", "bp_layered_kernelILi20ELi4ELb0EDF16_"), 0),   # (rocprofv3 leaves _Float16 mangled)
+    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float, 1>", 0), "ms_layered_f16": (("bp_layered_kernel<20, 4, false, _Float16, 1>", "bp_layered_kernelILi20ELi4ELb0EDF16_Li1E"), 0),   # (rocprofv3 leaves _Float16 mangled)
+    "bp_layered": ("bp_layered_kernel<20, 2, false, float, 0>", 0),
     "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
     "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true, false>", -1),   # (-1: the last two dispatches — the workspace probes launch this kernel too)
 }
@@ -787,7 +792,7 @@ def _cpu(c):
     return {"value": _r(c.get("value"), 6), "unit": c.get("unit", "frames/s"), "cores": c.get("cores"), "kind": c.get("kind"),
             "frames": c.get("frames"), "cores_visible": c.get("cores_visible"), "busy_cores_mean": _r(c.get("busy_cores_mean"), 4),
             "per_core": _r(c.get("frames_per_s_per_core"), 4), "survey_1thread": c.get("survey_single_thread_frames_per_s"),
-            "sample": "%s frames, %s single-threaded processes, own stopping rule, same H05/AWGN workload" % (c.get("frames"), c.get("cores"))}
+            "sample": "%s frames of the same H05/AWGN workload, %s 1-thread processes, own stopping rule" % (c.get("frames"), c.get("cores"))}
 
 
 def compact_line(d):
@@ -826,6 +831,10 @@ def compact_line(d):
     for k in ("fixed", "early_exit", "layered_fixed", "layered_exit", "layered_f16_fixed", "layered_f16_exit"):
         if ms.get(k):
             legs["minsum_" + k + " (parity unpinned)"] = _triple(ms[k])
+    sl = d.get("sumproduct_layered") or {}
+    for k in ("fixed", "early_exit", "f16_early_exit"):
+        if sl.get(k):
+            legs["spa_layered_" + k + " (FER-level parity)"] = _triple(sl[k])
     st = d.get("streamed") or {}
     for k in ("sum_product", "minsum_0.75"):
         if st.get(k):
@@ -999,6 +1008,16 @@ def main():
                 c, src = pmc_lookup(pmc, key)
                 r["roofline"] = roofline_fused(c, src, r["kernel_ms"], F, bp_bytes_per_frame(n, E, a.iters // 2, b=4 if key == "ms_layered" else 2))
             out["minsum_0.75"][name] = r
+        # ---- sum-product with the layered schedule: the reference's check rule (bp.h:49-57), another message order ----
+        sl = {"note": "layered schedule: a different algorithm from BeliefPropagationDecoder (bp.h:183-199 floods) — FER-level parity only: "
+                      "FER <= the flooding decoder's at half the iterations (tests/test_layered.py)"}
+        for key, name in (("bp_layered", "fixed"), ("bp_layered_exit", "early_exit"), ("bp_layered_f16_exit", "f16_early_exit")):
+            r = decode_leg(rig, batch, T[key], a.snr, ss, 1)
+            if key == "bp_layered":
+                c, src = pmc_lookup(pmc, key)
+                r["roofline"] = roofline_fused(c, src, r["kernel_ms"], F, bp_bytes_per_frame(n, E, a.iters // 2))
+            sl[name] = r
+        out["sumproduct_layered"] = sl
         # ---- the HBM-resident engine: messages [edge][frame] in HBM, one lane per frame ------------------
         st = {}
         for key, item in (("sum_product", "bp_streamed"), ("minsum_0.75", "ms_streamed")):

@@ -60,11 +60,14 @@ enum {
 /* BP message schedule */
 enum {
     ACG_LDPC_SCHEDULE_FLOODING = 0, /* the reference's schedule (bp.h:183-199): all checks, then all variables */
-    ACG_LDPC_SCHEDULE_LAYERED = 1   /* build-added, min-sum only: the block rows of a quasi-cyclic H (or, for any
-                                       other H, groups of checks that share no variable) are processed in sequence and the
-                                       posteriors are updated in place after every layer, so one sweep does the work of about
-                                       two flooding sweeps.  A DIFFERENT algorithm from the reference's: parity is FER-level
-                                       only (and min-sum itself is unpinned). Sum-product refuses it. */
+    ACG_LDPC_SCHEDULE_LAYERED = 1   /* build-added: the block rows of a quasi-cyclic H (or, for any other H, groups
+                                       of checks that share no variable) are processed in sequence and the posteriors are
+                                       updated in place after every layer, so one iteration does the work of about two
+                                       flooding sweeps.  A DIFFERENT algorithm from the reference's BeliefPropagationDecoder:
+                                       parity is FER-level only.  With ACG_LDPC_BP_MINSUM: normalised min-sum (parity unpinned
+                                       anyway); with ACG_LDPC_BP_SUMPRODUCT: the reference's check rule (bp.h:49-57) in the
+                                       layered message order — the reference's FER at about half its iterations.  fp32
+                                       posteriors; messages fp32, or fp16 with ACG_LDPC_PREC_F16. */
 };
 
 /* noise source for acg_ldpc_mc_run */

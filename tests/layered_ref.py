@@ -66,3 +66,60 @@ def layered_minsum(Hm, layers, y, snr, max_iter, scale, msg_dtype=np.float32):
         bits[idx] = hb[good]
         ok[idx] = 1
     return bits, ok, iters
+
+
+def layered_sumproduct(Hm, layers, y, snr, max_iter, sat=83.25 / 1.4426950408889634):
+    """float64 restatement of the SUM-PRODUCT variant of the layered kernel (the reference's check rule, bp.h:49-57, with
+    phi(x) = -log(tanh(x/2)) evaluated exactly; messages saturate at `sat` natural units like the kernel's).  The kernel works in
+    fp32 with its own phi, so agreement is a RATE (tests/test_layered.py), not word for word."""
+    Hm = np.asarray(Hm)
+    F, n = y.shape
+    var = 10.0 ** (-(snr / 10.0)) / 2.0
+    P = 2.0 * y.astype(np.float64) / var
+    edges = [np.nonzero(Hm[c])[0] for c in range(Hm.shape[0])]
+    R = [np.zeros((F, len(e))) for e in edges]
+    done = np.zeros(F, dtype=bool)
+    bits = np.zeros((F, n), dtype=np.uint8)
+    ok = np.zeros(F, dtype=np.uint8)
+    iters = np.full(F, max_iter, dtype=np.int32)
+
+    def phi(x):
+        with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+            return np.where(x >= 45.747713916956390, 0.0, -np.log(np.tanh(0.5 * x)))
+    for it in range(1, max_iter + 1):
+        live = ~done
+        if not live.any():
+            break
+        loud = np.zeros(F, dtype=bool)
+        for layer in layers:
+            for c in layer:
+                if c < 0:
+                    continue
+                v = edges[c]
+                p = P[:, v]
+                q = p - R[c]
+                mag = phi(np.abs(q))
+                # exclude-self sums formed directly (never total - own: an infinite term would turn into NaN), bp.h:50-55
+                others = np.stack([np.delete(mag, j, axis=1).sum(axis=1) for j in range(mag.shape[1])], axis=1)
+                out = np.minimum(phi(others), sat)
+                sq = np.signbit(q)
+                neg = np.logical_xor.reduce(sq, axis=1)[:, None] ^ sq
+                rn = np.where(neg, -out, out)
+                pn = q + rn
+                parity = np.logical_xor.reduce(np.signbit(p), axis=1)
+                loud |= parity | (np.signbit(pn) != np.signbit(p)).any(axis=1)
+                P[np.ix_(live, v)] = pn[live]
+                R[c][live] = rn[live]
+        newly = live & ~loud
+        bits[newly] = np.signbit(P[newly]).astype(np.uint8)
+        ok[newly] = 1
+        iters[newly] = it
+        done |= newly
+    rest = ~done
+    if rest.any() and max_iter > 0:
+        hb = np.signbit(P[rest]).astype(np.uint8)
+        good = ((hb @ Hm.T.astype(np.int64)) % 2 == 0).all(axis=1)
+        idx = np.nonzero(rest)[0][good]
+        bits[idx] = hb[good]
+        ok[idx] = 1
+    return bits, ok, iters

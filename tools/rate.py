@@ -67,7 +67,8 @@ def main():
         dec = A.MinSumDecoder(a.iters, 0.75, early_exit=a.exit, lanes_per_frame=a.lanes, engine=eng, precision=prec,
                               schedule=A.SCHEDULE_LAYERED if a.layered else A.SCHEDULE_FLOODING)
     else:
-        dec = A.BeliefPropagationDecoder(a.iters, early_exit=a.exit, lanes_per_frame=a.lanes, engine=eng, precision=prec)
+        dec = A.BeliefPropagationDecoder(a.iters, early_exit=a.exit, lanes_per_frame=a.lanes, engine=eng, precision=prec,
+                                         schedule=A.SCHEDULE_LAYERED if a.layered else A.SCHEDULE_FLOODING)
     h, _ = dec.handle(H)
     t_create = time.time() - t0
     F, n, nw = a.frames, H.n, (H.n + 31) // 32
