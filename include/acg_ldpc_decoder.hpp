@@ -198,13 +198,16 @@ private:
 // algo/bp.h:208-222
 class BeliefPropagationDecoder : public HipDecoderBase {
 public:
-    explicit BeliefPropagationDecoder(int max_iter) : _max_iter(max_iter) {}
+    // layered (build-added, default off = the reference's flooding schedule, bit-exact hard decisions): the same check rule with the
+    // posteriors updated per block row — the reference's FER at about half the iterations, FER-level parity only
+    explicit BeliefPropagationDecoder(int max_iter, bool layered = false) : _max_iter(max_iter), _layered(layered) {}
     std::string name() const override { return "BP"; }  // bp.h:218
 
 protected:
     void fill(acg_ldpc_params &p) const override {
         p.algo = ACG_LDPC_BP_SUMPRODUCT;
         p.max_iter = _max_iter;
+        p.schedule = _layered ? ACG_LDPC_SCHEDULE_LAYERED : ACG_LDPC_SCHEDULE_FLOODING;
     }
     std::pair<TCodeword, bool> finish(const std::vector<uint8_t> &bits, bool ok) const override {
         if (!ok) return {TCodeword(), false};  // bp.h:198
@@ -213,6 +216,7 @@ protected:
 
 private:
     int _max_iter;
+    bool _layered;
 };
 
 // algo/qp_admm.h:180-194 (same defaults)
