@@ -780,7 +780,10 @@ def _triple(leg, rl=None):
     if not leg:
         return None
     rl = rl if rl is not None else leg.get("roofline")
-    t = {"value": _r(leg.get("value"), 6), "frac": _r((rl or {}).get("frac"), 4), "bound": (rl or {}).get("bound")}
+    v = _r(leg.get("value"), 6)
+    t = {"value": int(v) if isinstance(v, float) and v >= 1e5 else v, "frac": _r((rl or {}).get("frac"), 4)}
+    if (rl or {}).get("bound") is not None:      # (legs without a counter pass: frac null, no bound)
+        t["bound"] = rl["bound"]
     if leg.get("fer") is not None:
         t["fer"] = _r(leg["fer"], 4)
     return t
@@ -1018,6 +1021,8 @@ def main():
                 r["roofline"] = roofline_fused(c, src, r["kernel_ms"], F, bp_bytes_per_frame(n, E, a.iters // 2))
             sl[name] = r
         out["sumproduct_layered"] = sl
+        # the same through the Monte-Carlo loop (AWGN kernel -> decode -> classification kernel, all on the device)
+        out["monte_carlo"]["bp%d_layered_%+.1fdB" % (a.iters // 2, a.snr)] = mc_leg(rig, H, cws, T["bp_layered_exit"], a.snr, F, ss)
         # ---- the HBM-resident engine: messages [edge][frame] in HBM, one lane per frame ------------------
         st = {}
         for key, item in (("sum_product", "bp_streamed"), ("minsum_0.75", "ms_streamed")):
