@@ -219,7 +219,9 @@ struct ScatteredAlloc {
         mapped.clear();
     }
     // -> true on success (va usable, read/write from `dev`)
-    bool create(size_t want, size_t chunk_bytes, int dev, bool shuffle) {
+    // spread > 1: `spread` times as many physical chunks are created and only every spread-th is kept (the others are released
+    // again at once), so the kept ones are spaced out over a `spread` times larger part of the device memory
+    bool create(size_t want, size_t chunk_bytes, int dev, bool shuffle, int spread = 1) {
         hipMemAllocationProp prop{};
         prop.type = hipMemAllocationTypePinned;
         prop.location.type = hipMemLocationTypeDevice;
@@ -235,13 +237,35 @@ struct ScatteredAlloc {
         }
         handles.reserve(n);
         mapped.assign(n, 0);
-        for (size_t i = 0; i < n; i++) {
-            hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
+        {
+            std::vector<hipMemGenericAllocationHandle_t> spare;
+            bool okc = true;
+            for (size_t i = 0; i < n * (size_t) std::max(spread, 1) && okc; i++) {
+                hipMemGenericAllocationHandle_t h;
+                if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
+                    okc = i >= n && handles.size() == n;   // out of memory while over-allocating: keep what there is if it suffices
+                    if (!okc && handles.size() < n && !spare.empty()) {  // not enough kept ones: take spares
+                        while (handles.size() < n && !spare.empty()) {
+                            handles.push_back(spare.back());
+                            spare.pop_back();
+                        }
+                        okc = handles.size() == n;
+                    }
+                    break;
+                }
+                if (handles.size() < n && i % (size_t) std::max(spread, 1) == 0) handles.push_back(h);
+                else spare.push_back(h);
+            }
+            while (handles.size() < n && !spare.empty()) {
+                handles.push_back(spare.back());
+                spare.pop_back();
+            }
+            for (auto &h : spare) (void) hipMemRelease(h);
+            if (handles.size() != n) {
+                (void) hipGetLastError();
                 release();
                 return false;
             }
-            handles.push_back(h);
         }
         // physical chunk i (creation order: neighbours in physical memory more often than not) -> virtual slot perm[i]
         std::vector<size_t> perm(n);
@@ -315,6 +339,7 @@ struct acg_ldpc_decoder {
     uint32_t *sws = nullptr;
     ScatteredAlloc sws_scattered;  // backing of sws when it was made of shuffled physical chunks (else sws is a hipMalloc)
     std::vector<float> sws_probe_ms;  // probe time of every workspace candidate that was tried (the fastest was kept)
+    int sws_spread = 1;               // the kept physical chunks are every sws_spread-th of those created
     int sgrid = 0;
     // ADMM
     AdmmDevice *admm = nullptr;
@@ -541,11 +566,17 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
         //                                         hipMalloc (round 2's "158 or 179 ms depending on the box"); one box gave 180 only
         //   physical chunks mapped into one       149-153 ms on one box (20 of 20), 152-180 ms (mostly 157-169) on another: never
         //   virtual range (hipMemCreate/hipMemMap) worse than hipMalloc, but still a draw per allocation
-        // What the draw is (the physical placement the driver hands out) cannot be seen or steered from user space, but it can be
-        // MEASURED: so a large workspace is allocated ACG_STREAM_WS_TRIES (default 3) times from 64 MiB chunks, each candidate is
-        // timed with a three-sweep launch of the decoder's own kernel over one tile per resident workgroup (about 10 ms), and the
-        // fastest is kept.  hipMalloc remains the fallback and the small-workspace path.  ACG_STREAM_WS_ALLOC = 0 / 1 / 2 / 3
-        // forces hipMalloc / contiguous / shuffled chunks / chunks in creation order (developer A/B only).
+        // What the draw is: how COMPACT the physical backing is.  Keeping only every K-th of K times as many chunks (the others
+        // are released at once) spaces the kept ones out over a K times larger part of the device memory, and on a box whose
+        // plain candidates all probed slow (20.1 ms, 180 ms per launch) K = 4 gave 158 ms and K = 16 gave 148 ms — the fast
+        // mode, every time since (a compact region keeps few DRAM banks in play for 768 concurrent streams; that reading fits
+        // every observation above, the physical addresses themselves are not visible).  So a workspace beyond the Infinity Cache
+        // is built from 64 MiB chunks spaced out 16-fold (ACG_STREAM_WS_SPREAD; costs ~3 s of decoder creation and, for a moment,
+        // 16 x the workspace in device memory — when that is not available the chunks that were obtained are used as they are).
+        // ACG_STREAM_WS_TRIES > 1 additionally times several candidates with a three-sweep launch of the decoder's own kernel
+        // and keeps the fastest (the probe is always taken and reported: 17 ms = fast, 20 ms = slow on configs[4]).
+        // hipMalloc remains the fallback and the small-workspace path.  ACG_STREAM_WS_ALLOC = 0 / 1 / 2 / 3 forces hipMalloc /
+        // contiguous / shuffled chunks / chunks in creation order (developer A/B only).
         const char *wa = getenv("ACG_STREAM_WS_ALLOC");
         const int mode = wa ? atoi(wa) : (ws_bytes >= ((size_t) 64 << 20) ? 2 : 0);
         hipError_t e = hipErrorUnknown;
@@ -554,19 +585,24 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
             const char *cm = getenv("ACG_STREAM_WS_CHUNK_MB");
             const size_t chunk = (size_t) (cm ? atol(cm) : 64) << 20;
             const char *tr = getenv("ACG_STREAM_WS_TRIES");
-            int tries = tr ? atoi(tr) : 3;
-            // the draw only matters beyond the Infinity Cache, and the probe needs the ring kernel and room for its symbols
+            int tries = tr ? atoi(tr) : 1;
+            // the placement only matters beyond the Infinity Cache, and the probe needs the ring kernel and room for its symbols
             const int64_t probe_frames = (int64_t) d->sgrid * 64;
-            if (!d->sring || ws_bytes <= ((size_t) 512 << 20) || (size_t) probe_frames * c.n * 4 > ws_bytes) tries = 1;
+            const bool big = ws_bytes > ((size_t) 512 << 20);
+            const bool can_probe = d->sring && big && (size_t) probe_frames * c.n * 4 <= ws_bytes;
+            if (!can_probe) tries = 1;
             tries = std::max(1, std::min(tries, 6));
+            const char *sp = getenv("ACG_STREAM_WS_SPREAD");
+            const int spread = big ? std::max(1, std::min(sp ? atoi(sp) : 16, 64)) : 1;
             std::vector<ScatteredAlloc> cand((size_t) tries);
             int best = -1;
             float best_ms = 0;
             d->sws_probe_ms.clear();
+            d->sws_spread = spread;
             for (int k = 0; k < tries; k++) {
-                if (!cand[k].create(ws_bytes, chunk, d->device, mode == 2)) break;
+                if (!cand[k].create(ws_bytes, chunk, d->device, mode == 2, spread)) break;
                 float ms = 0;
-                if (tries > 1) {
+                if (can_probe) {
                     DecodeArgs pa{};
                     pa.y = cand[k].va;           // any readable memory will do as symbols: the probe times traffic, not decoding
                     pa.y_is_f64 = 0;
@@ -1076,7 +1112,7 @@ static std::string describe(const acg_ldpc_decoder *d) {
                  d->sws_scattered.va ? "flooding workspace=mapped-chunks" : "flooding workspace=hipMalloc");
         if (!d->sws_probe_ms.empty()) {
             std::string t = b;
-            t += " workspace_probe_ms=";
+            t += " workspace_spread=" + std::to_string(d->sws_spread) + " workspace_probe_ms=";
             for (size_t i = 0; i < d->sws_probe_ms.size(); i++) {
                 char q[32];
                 snprintf(q, sizeof q, "%s%.2f", i ? "/" : "", d->sws_probe_ms[i]);

@@ -77,6 +77,30 @@ def main():
                 run("alloc_mode=%d after_churn_%d" % (mode, k), 3)
                 run("alloc_mode=%d recreate_%d" % (mode, k), 3)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "final":
+        # the library default (chunks spaced out 16-fold, one candidate) against plain chunks, alternating over allocation histories
+        for rep in range(4):
+            for sp in ("1", None):
+                if sp is None:
+                    os.environ.pop("ACG_STREAM_WS_SPREAD", None)
+                else:
+                    os.environ["ACG_STREAM_WS_SPREAD"] = sp
+                if rep:
+                    churn(16 if rep % 2 else 48)
+                t0 = time.time()
+                run("%s rep %d" % ("plain chunks" if sp else "default (spread 16)", rep), 3)
+                print("   (decoder creation + 4 launches: %.1f s)" % (time.time() - t0), flush=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "spread":
+        # is the slow mode a COMPACT physical region (few DRAM banks / rows in play)?  keep every K-th of K times as many chunks
+        os.environ["ACG_STREAM_WS_TRIES"] = "3"
+        for rep in range(2):
+            for k in (1, 4, 16, 30):
+                os.environ["ACG_STREAM_WS_SPREAD"] = str(k)
+                t0 = time.time()
+                run("spread=%d rep %d" % (k, rep), 2)
+                print("   (%.1f s)" % (time.time() - t0), flush=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "tries":
         # best-of-K workspace candidates (what the library does by default, K = 3) against K = 1, alternating
         for rep in range(4):
