@@ -38,7 +38,7 @@ const void *bp_block_kernel_ptr(int algo, int f64, int L, bool mc, bool idxlds, 
 const void *bp_kernel_ptr_dbg(int f64, int L);
 const void *bp_block_kernel_ptr_dbg(int f64);
 const void *bp_pair_kernel_ptr(int L, bool regular);
-const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16, int algo);
+const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16, int algo, bool mc);
 hipError_t bp_layered_launch(const void *kernel, const LayerTables &t, const DecodeArgs &a, int grid, int block, size_t lds, hipStream_t s);
 const void *bp_streamed_ptr(int algo, int f64);
 const void *bp_streamed_ring_ptr(int algo, bool nt);
@@ -694,7 +694,7 @@ static int decoder_setup_layered(acg_ldpc_decoder *d) {
     t.tab_lds_bytes = (int) (((size_t) ll.e_pad * 2 + 15) & ~(size_t) 15);
     // frame stride = G (mod 32) words: the lanes of the frames sharing a wavefront then fall into disjoint LDS banks
     t.r_words = lay_f16 ? (ll.e_pad + 1) / 2 : ll.e_pad;
-    int words = t.p_words + t.r_words + t.nwords;
+    int words = t.p_words + t.r_words + t.nwords + 1;   // (+1: the Monte-Carlo instance's raw-channel error count)
     while (words % 32 != ll.G % 32) words++;
     t.lds_bytes_per_frame = words * 4;
     const int fpw = 64 / ll.G;
@@ -726,18 +726,19 @@ static int decoder_setup_layered(acg_ldpc_decoder *d) {
     // ACG_LAY_ARITH=1 (developer A/B): compute the positions of a quasi-cyclic H in the hot loop instead of reading the table
     const int lay_algo = d->p.algo == ACG_LDPC_BP_MINSUM ? 1 : 0;
     const bool qc_arith = ll.qc && ll.G == 20 && !lay_f16 && lay_algo == 1 && getenv("ACG_LAY_ARITH") != nullptr;
-    const void *kp = bp_layered_kernel_ptr(ll.G, waves, qc_arith, lay_f16, lay_algo);
-    if (!kp) {
-        set_error("no layered kernel instance for this group width");
-        return 3;
+    for (int mc = 0; mc < 2; mc++) {
+        const void *kp = bp_layered_kernel_ptr(ll.G, waves, qc_arith && !mc, lay_f16, lay_algo, mc != 0);
+        if (!kp) {
+            set_error("no layered kernel instance for this group width");
+            return 3;
+        }
+        if (d->lds_block > 64 * 1024) HIP_OK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block));
+        int occ = 0;
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, d->block, d->lds_block));
+        if (occ < 1) occ = 1;
+        d->kernel[mc] = kp;
+        d->grid_cap[mc] = occ * d->cu_count;
     }
-    if (d->lds_block > 64 * 1024) HIP_OK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int) d->lds_block));
-    int occ = 0;
-    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, d->block, d->lds_block));
-    if (occ < 1) occ = 1;
-    d->kernel[0] = kp;
-    d->kernel[1] = nullptr;   // Monte-Carlo runs go AWGN kernel -> decode -> classification kernel
-    d->grid_cap[0] = d->grid_cap[1] = occ * d->cu_count;
     d->tab.lds_bytes_per_frame = t.lds_bytes_per_frame;
     return 0;
 }
@@ -1198,13 +1199,10 @@ static int launch_decode(acg_ldpc_decoder *d, DecodeArgs &a, hipStream_t s) {
             HIP_OK(bp_streamed_launch(d->skernel, d->stab, a, d->sws, grid, W * 64, s));
         }
     } else if (d->layered) {
-        if (a.mc) {
-            set_error("internal: the layered kernel has no in-kernel generator");
-            return 11;
-        }
+        const int mc = a.mc ? 1 : 0;
         const int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
-        const int grid = (int) std::min<int64_t>(blocks, d->grid_cap[0]);
-        HIP_OK(bp_layered_launch(d->kernel[0], d->ltab, a, grid, d->block, d->lds_block, s));
+        const int grid = (int) std::min<int64_t>(blocks, d->grid_cap[mc]);
+        HIP_OK(bp_layered_launch(d->kernel[mc], d->ltab, a, grid, d->block, d->lds_block, s));
     } else {
         int64_t blocks = (a.frames + d->frames_per_block - 1) / d->frames_per_block;
         const int mc = a.mc ? 1 : 0;
@@ -1606,7 +1604,7 @@ static int acg_ldpc_mc_run_impl(acg_ldpc_decoder *d, const acg_ldpc_mc_cfg *cfg,
     int rc = 0;
     if (cfg->noise == ACG_LDPC_NOISE_HOST_MT19937) {
         rc = mc_run_host_noise(d, cfg, res);
-    } else if (d->streamed || d->pair || d->layered || (d->admm && admm_device_unfused_mc(d->admm, nullptr, nullptr))) {
+    } else if (d->streamed || d->pair || (d->layered && getenv("ACG_LAY_UNFUSED_MC")) || (d->admm && admm_device_unfused_mc(d->admm, nullptr, nullptr))) {
         // AWGN kernel -> decode -> classify kernel, in bounded chunks, all on the device.  Used by the streamed BP
         // engine (no in-kernel generator) and by the workgroup-per-frame QP-ADMM kernel, whose fused Monte-Carlo
         // variant needs 156 VGPRs (3 waves/SIMD) against 117 (4) for the plain decode: 1.6 M vs 2.7 M frames/s.

@@ -219,7 +219,11 @@ __device__ __forceinline__ bool lgroup_any(bool pred, int g) {
 // QCA: the hot loop computes the posterior addresses of a quasi-cyclic H arithmetically (no table read); the table is still
 // built once per workgroup for the rare explicit syndrome pass.
 // ALGO: 1 = normalised min-sum, 0 = sum-product (phi domain)
-template <int G, int WAVES, bool QCA, typename RT, int ALGO>
+// MC: Monte-Carlo mode — the frame's AWGN symbols are generated in the kernel (Philox4x32-10 keyed on (seed, global frame, symbol
+// quad) + Box-Muller: the same symbols, bit for bit, as awgn_kernel and the flooding kernels produce), the decoded word is
+// classified against the sent one at exit and the seven counters of experiment.h:25-68,109-120 are accumulated per group and
+// flushed with one atomic per counter per group when the kernel ends.
+template <int G, int WAVES, bool QCA, typename RT, int ALGO, bool MC>
 __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTables t, const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int FPW = 64 / G;
@@ -257,6 +261,7 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
     float *P = reinterpret_cast<float *>(base);
     RT *R = reinterpret_cast<RT *>(P + t.p_words);
     uint32_t *OB = reinterpret_cast<uint32_t *>(P + t.p_words + t.r_words);
+    uint32_t *HAMW = OB + t.nwords;   // MC: raw-channel error count of the frame (one word; the host reserves it)
     const float scale = a.ms_scale;
     const int NL = t.n_layers;
 
@@ -266,6 +271,9 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
     bool active = false, want = lane_used, need_init = false, latched = false;
     int it = 0;             // iterations (rounds over all layers) this frame has been through
     uint32_t noisy_acc = 0; // sign bit: some step of the current round was not quiet for this lane's checks
+    int ham = 0;            // MC: raw-channel errors of the current frame
+    unsigned int acc_correct = 0, acc_pseudo = 0, acc_total = 0;
+    unsigned long long acc_ham = 0, acc_ham_ok = 0, acc_ham_wrong = 0, acc_iters = 0;
 
     auto emit = [&](const bool out_now, const bool fail_now) {
         if (__ballot(out_now || fail_now) != 0ull) {
@@ -282,6 +290,23 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
                 if (l == 0) {
                     if (a.out_ok) a.out_ok[frame] = out_now ? 1 : 0;
                     if (a.out_iters) a.out_iters[frame] = std::min(it, a.max_iter);
+                }
+                if (MC) {
+                    bool neq = false;
+                    const int64_t gf = a.first_frame + frame;
+                    for (int w = l; w < t.nwords; w += G) {
+                        const uint32_t cwv = a.cw_packed ? a.cw_packed[(size_t) (gf % a.n_cw) * t.nwords + w] : 0u;
+                        neq |= (OB[w] != cwv);
+                    }
+                    const bool differ = lgroup_any<G>(neq, g);   // every lane of the group is in this branch together
+                    const bool correct = out_now && !differ;     // experiment.h:110-114
+                    acc_correct += correct;
+                    acc_pseudo += (out_now && differ);            // experiment.h:115-116
+                    acc_total += 1;
+                    acc_ham += ham;
+                    acc_ham_ok += correct ? ham : 0;
+                    acc_ham_wrong += correct ? 0 : ham;
+                    acc_iters += std::min(it, a.max_iter);
                 }
                 latched = true;
             }
@@ -348,13 +373,44 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
         // ---- (re)start groups on a new frame: P = channel LLR (channel.h:14-16), R = 0 ------------------------------------
         if (__ballot(need_init) != 0ull) {
             lwave_sync();
-            if (need_init) {
-                for (int v = l; v < t.n; v += G) {
-                    float llr;
-                    if (a.y_is_f64) llr = (float) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + v] / a.var);
-                    else llr = (float) ((double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + v] * a.inv_var2);
-                    P[v] = (ALGO == 0) ? llr * (float) Dom<float>::scale : llr;
+            if (MC) {
+                if (need_init && l == 0) *HAMW = 0u;
+                lwave_sync();
+            }
+            if (need_init && MC) {
+                // transmit (channel.h:18-26) + llr (channel.h:14-16) + HammingDistanceTracker (experiment.h:33-46)
+                const int64_t gf = a.first_frame + frame;
+                const uint32_t *cw = a.cw_packed ? a.cw_packed + (size_t) (gf % a.n_cw) * t.nwords : nullptr;
+                int my_ham = 0;
+                const int nq = (t.n + 3) >> 2;
+                for (int qd = l; qd < nq; qd += G) {
+                    uint32_t rr[4];
+                    philox4x32_10((uint32_t) gf, (uint32_t) (gf >> 32), (uint32_t) qd, 0u, (uint32_t) a.seed, (uint32_t) (a.seed >> 32), rr);
+                    float z[4];
+                    box_muller(rr[0], rr[1], z[0], z[1]);
+                    box_muller(rr[2], rr[3], z[2], z[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int v = 4 * qd + e;
+                        if (v < t.n) {
+                            const uint32_t bit = cw ? ((cw[v >> 5] >> (v & 31)) & 1u) : 0u;
+                            const float yv = __builtin_fmaf(a.sigma, z[e], bit ? -1.0f : 1.0f);   // explicit fma: same symbol in every kernel
+                            my_ham += ((!bit && yv <= 0.0f) || (bit && yv > 0.0f)) ? 1 : 0;
+                            const float llr = (float) ((double) yv * a.inv_var2);
+                            P[v] = (ALGO == 0) ? llr * (float) Dom<float>::scale : llr;
+                        }
+                    }
                 }
+                if (my_ham) atomicAdd(HAMW, (uint32_t) my_ham);
+            }
+            if (need_init) {
+                if (!MC)
+                    for (int v = l; v < t.n; v += G) {
+                        float llr;
+                        if (a.y_is_f64) llr = (float) (2 * reinterpret_cast<const double *>(a.y)[(size_t) frame * t.n + v] / a.var);
+                        else llr = (float) ((double) reinterpret_cast<const float *>(a.y)[(size_t) frame * t.n + v] * a.inv_var2);
+                        P[v] = (ALGO == 0) ? llr * (float) Dom<float>::scale : llr;
+                    }
                 for (int w = t.n + l; w < t.p_words; w += G) P[w] = INFINITY;   // neutral cell: never the minimum, sign +
                 for (int w = l; w < t.e_pad; w += G) R[w] = (RT) 0.0f;
                 it = 0;
@@ -362,6 +418,7 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
                 need_init = false;
             }
             lwave_sync();
+            if (MC && active && it == 0) ham = (int) *HAMW;   // (groups that were not re-initialised re-read their own count)
         }
         // ---- one iteration: every layer in turn, posteriors updated in place ------------------------------------------------
         for (int b = 0; b < NL; ++b) {
@@ -379,31 +436,41 @@ __global__ void __launch_bounds__(WAVES * 64) bp_layered_kernel(const LayerTable
         }
         it += active ? 1 : 0;
     }
-}
-
-template <int G, bool QCA, typename RT, int ALGO>
-static const void *layered_ptr_w(int waves) {
-    switch (waves) {
-        case 1: return (const void *) bp_layered_kernel<G, 1, QCA, RT, ALGO>;
-        case 2: return (const void *) bp_layered_kernel<G, 2, QCA, RT, ALGO>;
-        default: return (const void *) bp_layered_kernel<G, 4, QCA, RT, ALGO>;
+    if (MC && lane_used && l == 0 && acc_total) {
+        atomicAdd(&a.counters[MC_CORRECT], (unsigned long long) acc_correct);
+        atomicAdd(&a.counters[MC_PSEUDO], (unsigned long long) acc_pseudo);
+        atomicAdd(&a.counters[MC_TOTAL], (unsigned long long) acc_total);
+        atomicAdd(&a.counters[MC_HAM], acc_ham);
+        atomicAdd(&a.counters[MC_HAM_OK], acc_ham_ok);
+        atomicAdd(&a.counters[MC_HAM_WRONG], acc_ham_wrong);
+        atomicAdd(&a.counters[MC_ITERS], acc_iters);
     }
 }
-template <int G>
+
+template <int G, bool QCA, typename RT, int ALGO, bool MC>
+static const void *layered_ptr_w(int waves) {
+    switch (waves) {
+        case 1: return (const void *) bp_layered_kernel<G, 1, QCA, RT, ALGO, MC>;
+        case 2: return (const void *) bp_layered_kernel<G, 2, QCA, RT, ALGO, MC>;
+        default: return (const void *) bp_layered_kernel<G, 4, QCA, RT, ALGO, MC>;
+    }
+}
+template <int G, bool MC>
 static const void *layered_ptr_g(int waves, bool f16, int algo) {
-    if (algo == 0) return f16 ? layered_ptr_w<G, false, _Float16, 0>(waves) : layered_ptr_w<G, false, float, 0>(waves);
-    return f16 ? layered_ptr_w<G, false, _Float16, 1>(waves) : layered_ptr_w<G, false, float, 1>(waves);
+    if (algo == 0) return f16 ? layered_ptr_w<G, false, _Float16, 0, MC>(waves) : layered_ptr_w<G, false, float, 0, MC>(waves);
+    return f16 ? layered_ptr_w<G, false, _Float16, 1, MC>(waves) : layered_ptr_w<G, false, float, 1, MC>(waves);
 }
 
 // algo: 0 sum-product, 1 min-sum.  qc_arith: positions computed in the hot loop instead of read from the table (G = 20, fp32
-// min-sum only: a measured alternative, 14 % slower — DESIGN §3d); f16: messages stored in half precision
-const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16, int algo) {
-    if (qc_arith) return (G == 20 && !f16 && algo == 1) ? layered_ptr_w<20, true, float, 1>(waves) : nullptr;
+// min-sum decode only: a measured alternative, 14 % slower — DESIGN §3d); f16: messages stored in half precision; mc: the
+// Monte-Carlo instance (noise generated and words classified in the kernel)
+const void *bp_layered_kernel_ptr(int G, int waves, bool qc_arith, bool f16, int algo, bool mc) {
+    if (qc_arith) return (G == 20 && !f16 && algo == 1 && !mc) ? layered_ptr_w<20, true, float, 1, false>(waves) : nullptr;
     switch (G) {
-        case 16: return layered_ptr_g<16>(waves, f16, algo);
-        case 20: return layered_ptr_g<20>(waves, f16, algo);
-        case 32: return layered_ptr_g<32>(waves, f16, algo);
-        case 64: return layered_ptr_g<64>(waves, f16, algo);
+        case 16: return mc ? layered_ptr_g<16, true>(waves, f16, algo) : layered_ptr_g<16, false>(waves, f16, algo);
+        case 20: return mc ? layered_ptr_g<20, true>(waves, f16, algo) : layered_ptr_g<20, false>(waves, f16, algo);
+        case 32: return mc ? layered_ptr_g<32, true>(waves, f16, algo) : layered_ptr_g<32, false>(waves, f16, algo);
+        case 64: return mc ? layered_ptr_g<64, true>(waves, f16, algo) : layered_ptr_g<64, false>(waves, f16, algo);
         default: return nullptr;
     }
 }

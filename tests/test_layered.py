@@ -124,6 +124,38 @@ def test_layered_ragged_batches_and_float_symbols(A, oracle, matrices):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["minsum", "bp"])
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_layered_monte_carlo_fused_equals_unfused(A, matrices, algo, prec, monkeypatch):
+    """the Monte-Carlo instance of the layered kernel (noise generated and words classified in the kernel) gives the same seven
+    counters as AWGN kernel -> decode kernel -> classification kernel on the same global frames, for any split into shards"""
+    H = A.ParityCheckMatrix(matrices["H05"])
+    G, _ = H.get_orthogonal()
+    cws = A.gen_random_codewords(G, 1000, 239239239)
+    pr = A.PREC_F16 if prec == "f16" else A.PREC_DEFAULT
+
+    def make():
+        if algo == "bp":
+            return A.BeliefPropagationDecoder(20, schedule=A.SCHEDULE_LAYERED, precision=pr)
+        return A.MinSumDecoder(20, 0.75, schedule=A.SCHEDULE_LAYERED, precision=pr)
+    F = 50000
+    for snr in (-2.0, 1.0):
+        d = make()
+        fused = A.run_experiment(d, cws, H, snr, frames=F, noise="device", seed=9).as_vector()
+        parts = sum(A.run_experiment(d, cws, H, snr, frames=c, first_frame=lo, noise="device", seed=9).as_vector()
+                    for lo, c in ((0, 12345), (12345, 1), (12346, F - 12346)))
+        d.close()
+        monkeypatch.setenv("ACG_LAY_UNFUSED_MC", "1")
+        d = make()
+        unfused = A.run_experiment(d, cws, H, snr, frames=F, noise="device", seed=9).as_vector()
+        d.close()
+        monkeypatch.delenv("ACG_LAY_UNFUSED_MC")
+        assert (fused == unfused).all(), (algo, prec, snr, fused, unfused)
+        assert (fused == parts).all(), (algo, prec, snr, fused, parts)
+        assert fused[2] == F and fused[3] == fused[4] + fused[5] and fused[0] > 0
+
+
+@pytest.mark.gpu
 def test_layered_ragged_graph(A, oracle):
     """a matrix that is neither quasi-cyclic nor regular: an empty check, a degree-3 check among degree-6 ones, isolated
     variables, a degree-1 check — greedy-coloured layers of several degrees with partly filled lanes"""
