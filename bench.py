@@ -569,8 +569,8 @@ def pmc_probe_child(a):
 PROBE_KERNEL = {  # item -> (substring of the rocprofv3 kernel name, position among the probe's uses of that kernel)
     "bp_fused": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 0), "bp_exit": ("bp_fused_kernel<float, 8, 32, 0, false, true, 12, false>", 1),
     "bp_mc": ("bp_fused_kernel<float, 8, 32, 0, true, true, 12, false>", 0), "bp_streamed": ("bp_streamed_ring_kernel<0, false, false>", 0),
-    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float, 1>", 0), "ms_layered_f16": (("bp_layered_kernel<20, 4, false, _Float16, 1>", "bp_layered_kernelILi20ELi4ELb0EDF16_Li1E"), 0),   # (rocprofv3 leaves _Float16 mangled)
-    "bp_layered": ("bp_layered_kernel<20, 2, false, float, 0>", 0),
+    "ms_streamed": ("bp_streamed_ring_kernel<1, false, false>", 0), "ms_layered": ("bp_layered_kernel<20, 2, false, float, 1, false>", 0), "ms_layered_f16": (("bp_layered_kernel<20, 4, false, _Float16, 1, false>", "bp_layered_kernelILi20ELi4ELb0EDF16_Li1ELb0EE"), 0),   # (rocprofv3 leaves _Float16 mangled)
+    "bp_layered": ("bp_layered_kernel<20, 2, false, float, 0, false>", 0),
     "qpadmm": ("admm_block_kernel<double, false, 3, true>", 0),
     "c5_block_ms": ("bp_block_kernel<float, 1024, 1, false, false, true, false, true>", 0), "c5_pair_f16_ms": ("bp_pair_kernel<1024, true>", 0), "c5_streamed_ms": ("bp_streamed_ring_kernel<1, true, false>", -1),   # (-1: the last two dispatches — the workspace probes launch this kernel too)
 }

@@ -107,6 +107,22 @@ def test_every_probed_item_has_a_kernel_pattern():
         assert isinstance(pos, int)
 
 
+def test_probe_patterns_name_kernels_of_the_built_library():
+    """every kernel bench.py asks rocprofv3 about exists under that (demangled) name in libacg_ldpc_hip.so — a template
+    parameter added to a kernel silently emptied two counter sets in round 3"""
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import valu_mix
+    if not os.path.exists(os.path.join(valu_mix.LLVM, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    import acg_alp_ldpc_amd as A
+    A.build()
+    names = list(valu_mix.disassemble(valu_mix.default_lib()))
+    for item, (pat, _) in bench.PROBE_KERNEL.items():
+        pats = (pat,) if isinstance(pat, str) else pat
+        assert any(q in k for q in pats for k in names), (item, pats)
+
+
 def test_usable_cores_reads_affinity_not_cpu_count(monkeypatch):
     import bench
     monkeypatch.setattr(os, "cpu_count", lambda: 256)
