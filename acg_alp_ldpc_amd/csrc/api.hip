@@ -593,7 +593,12 @@ static int decoder_setup_streamed(acg_ldpc_decoder *d) {
             if (!can_probe) tries = 1;
             tries = std::max(1, std::min(tries, 6));
             const char *sp = getenv("ACG_STREAM_WS_SPREAD");
-            const int spread = big ? std::max(1, std::min(sp ? atoi(sp) : 16, 64)) : 1;
+            int spread = big ? std::max(1, std::min(sp ? atoi(sp) : 16, 64)) : 1;
+            if (spread > 1) {   // never ask for more than ~80 % of the memory that is free right now
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ws_bytes > 0)
+                    spread = (int) std::max<size_t>(1, std::min<size_t>((size_t) spread, (size_t) ((double) free_b * 0.8 / (double) ws_bytes)));
+            }
             std::vector<ScatteredAlloc> cand((size_t) tries);
             int best = -1;
             float best_ms = 0;
@@ -1126,7 +1131,8 @@ static std::string describe(const acg_ldpc_decoder *d) {
                                "idx_lds=%d idx_reg=%d schedule=%s",
                  algo, d->layered ? "bp_layered_kernel" : (d->pair ? "bp_pair_kernel" : (d->variant < 0 ? "bp_block_kernel" : "bp_fused_kernel")), d->L, d->f64, d->block,
                  d->frames_per_block, d->lds_block, d->grid_cap[0], d->variant < 0 ? (int) d->blk_idxlds : (d->variant > 0), (int) d->blk_idxreg,
-                 d->p.schedule == ACG_LDPC_SCHEDULE_LAYERED ? "layered" : "flooding");
+                 d->p.schedule == ACG_LDPC_SCHEDULE_LAYERED ? (d->p.precision == ACG_LDPC_PREC_F16 ? "layered messages=fp16" : "layered messages=fp32")
+                                                            : "flooding");
     }
     return b;
 }
