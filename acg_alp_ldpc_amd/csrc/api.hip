@@ -1066,6 +1066,11 @@ void acg_ldpc_decoder_destroy(acg_ldpc_decoder *d) {
     if (!d) return;
     (void) hipSetDevice(d->device);
     if (d->stream) (void) hipStreamSynchronize(d->stream);
+    // launches of this handle that are still in flight on CALLER streams (acg_ldpc_decode_batch_dev is asynchronous): every
+    // launch recorded the stop event of its ring slot on its own stream — wait for them before the tables go (a handle can be
+    // destroyed by the LRU of a host mirror while the caller's stream is still busy)
+    for (int k = 0; k < acg_ldpc_decoder::WORK_RING; k++)
+        if (d->ring_used[k] && d->ring_ev[k]) (void) hipEventSynchronize(d->ring_ev[k]);
     for (void *p : d->dev_allocs) (void) hipFree(p);
     if (d->admm) admm_device_destroy(d->admm);
     if (d->sws_scattered.va) d->sws_scattered.release();

@@ -107,6 +107,42 @@ def test_one_decoder_many_matrices_from_threads():
 
 
 @pytest.mark.gpu
+def test_eviction_waits_for_asynchronous_launches():
+    """acg_ldpc_decode_batch_dev is asynchronous on the caller's stream: launching through ONE decoder object on 12 distinct H
+    back to back evicts (destroys) the first handles while their kernels may still be queued — destroy waits for the launches of
+    the handle (the stop events of its work-ring slots) before it frees the tables.  Results equal the synchronous ones."""
+    import torch
+    import acg_alp_ldpc_amd as A
+    rng = np.random.default_rng(11)
+    F, n = 32768, 96
+    mats = [A.ParityCheckMatrix(A.regular_ldpc(48, 96, 3, 6, seed=900 + s)) for s in range(12)]
+    ys = [rng.normal(1.0, 0.8, size=(F, n)).astype(np.float32) for _ in mats]
+    ref = A.BeliefPropagationDecoder(40, early_exit=False)
+    want = []
+    for H, y in zip(mats, ys):
+        b, ok, it = ref.decode_batch(H, y, 1.0)
+        want.append((np.packbits(b, axis=1, bitorder="little"), ok, it))
+        ref.close()
+    dec = A.BeliefPropagationDecoder(40, early_exit=False)
+    stream = torch.cuda.Stream()
+    outs = []
+    for H, y in zip(mats, ys):
+        yd = torch.from_numpy(y).cuda()
+        bits = torch.zeros((F, 3), dtype=torch.int32, device="cuda")
+        ok = torch.zeros(F, dtype=torch.uint8, device="cuda")
+        its = torch.zeros(F, dtype=torch.int32, device="cuda")
+        stream.wait_stream(torch.cuda.current_stream())
+        dec.decode_batch_dev(H, yd.data_ptr(), False, F, 1.0, bits.data_ptr(), ok.data_ptr(), its.data_ptr(), stream.cuda_stream)
+        outs.append((yd, bits, ok, its))
+        assert dec.live_handles() <= dec.max_handles
+    torch.cuda.synchronize()
+    for (yd, bits, ok, its), (wb, wok, wit) in zip(outs, want):
+        got = bits.cpu().numpy().view(np.uint8)[:, :12]
+        assert (ok.cpu().numpy() == wok).all() and (its.cpu().numpy() == wit).all() and (got == wb).all()
+    dec.close()
+
+
+@pytest.mark.gpu
 def test_cxx_adaptor_100_matrices_bounded(tmp_path):
     """the C++ mirror (include/acg_ldpc_decoder.hpp): 100 distinct H through one BeliefPropagationDecoder and one
     QPADMMDecoder, from 4 host threads at once"""
